@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- ICP iterations/s on 64k-point scan pairs (BASELINE.json metric, configs[1]).
+
+One "step" = one pass of the hot path over this rank's batch of synthetic scan pairs:
+`--iters` (50) ICP iterations on every pair, starting from the identity pose, inputs
+already resident in HBM, followed (N > 1) by the all-gather of the per-pair poses.
+Scan pairs shard one batch per GPU with no data-path collective besides that pose
+all-gather (weak scaling: per-GPU work is fixed).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(npairs, n, m):
+    """20 n + 12 m bytes per pair per iteration (read source xyz 12 n, read
+    target xyz 12 m, write idx + sqd 8 n)."""
+    return npairs * (20 * n + 12 * m)
+
+
+def cpu_baseline(points, iters, budget_s=20.0):
+    """The oracle (kd-tree port of the reference's PCL/FLANN + Eigen path), one thread, on a
+    bounded sample: whole 50-iteration runs of pair 0, 1, ... until ~budget_s is spent."""
+    import _oracle as O
+    from gpscalibration_amd import synth
+    done_iters, spent, pairs = 0, 0.0, 0
+    build = 0.0
+    while spent < budget_s and pairs < 4:
+        tgt, src, _ = synth.scan_pair(points, pairs)
+        t0 = time.perf_counter()
+        kd = O.KdTree(tgt)
+        t1 = time.perf_counter()
+        kd.icp_run(src, iters)
+        t2 = time.perf_counter()
+        build += t1 - t0
+        spent += t2 - t1
+        done_iters += iters
+        pairs += 1
+    return {
+        "value": done_iters / spent, "unit": "ICP iterations/s", "cores": 1, "kind": "port",
+        "sample": "%d pair(s) x %d iterations, %d-point scans, kd-tree prebuilt (%.3f s/build), %.1f s CPU"
+                  % (pairs, iters, points, build / max(pairs, 1), spent),
+        "value_incl_build": done_iters / (spent + build),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--points", type=int, default=65536)
+    ap.add_argument("--pairs", type=int, default=64, help="scan pairs per GPU (the batch of one step)")
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+
+    from gpscalibration_amd import Context, synth
+    from gpscalibration_amd.parallel import shard_range
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = Context(local_rank)
+
+    # ---- this rank's shard of the global pair list (weak scaling: args.pairs per GPU)
+    total_pairs = args.pairs * world
+    lo, hi = shard_range(total_pairs, rank, world)
+    npairs, n = hi - lo, args.points
+    tg, to, sr, so, _ = synth.scan_batch(npairs, n, first_pair=lo)
+    d_tg = torch.from_numpy(tg).cuda()
+    d_sr = torch.from_numpy(sr).cuda()
+    torch.cuda.synchronize()
+    sb = ctx.scan_batch(d_tg, to, d_sr, so)  # index build + source grouping
+    build_s = sb.build_seconds
+    d_T = torch.empty((npairs, 4, 4), dtype=torch.float64, device="cuda")
+    d_all = torch.empty((total_pairs, 4, 4), dtype=torch.float64, device="cuda") if world > 1 else d_T
+
+    def step():
+        sb.set_pose(None)
+        sb.icp(args.iters, want_err=False, T_out=d_T)
+        if world > 1:
+            ctx.sync()  # poses are produced on the library's stream
+            dist.all_gather_into_tensor(d_all.view(-1), d_T.view(-1))
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    ms_per_step = 1e3 * dt / max(args.steps, 1)
+    value = total_pairs * args.iters * args.steps / dt
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (icp_step_kernel): event-bracketed launches
+        sb.set_pose(None)
+        _, _, ms = sb.icp(args.iters, want_err=False, profile=True)
+        kern_ms = float(np.mean(ms))
+        abytes = algorithmic_bytes(npairs, n, n)
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    rec = json.load(f)
+                key = "pairs%d_points%d" % (npairs, n)
+                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        # ---- single-pair latency-bound rate, for DESIGN.md (not `value`)
+        off1 = np.array([0, n], dtype=np.int64)
+        sb1 = ctx.scan_batch(d_tg[:n], off1, d_sr[:n], off1)
+        for _ in range(2):
+            sb1.set_pose(None)
+            sb1.icp(args.iters, want_err=False, T_out=d_T[:1])
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            sb1.set_pose(None)
+            sb1.icp(args.iters, want_err=False, T_out=d_T[:1])
+        ctx.sync()
+        single = 5 * args.iters / (time.perf_counter() - t1)
+        sb1.close()
+        out = {
+            "metric": "ICP iterations/sec (64k-pt scans)", "value": value, "unit": "ICP iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic %d-point scan pairs, %d ICP iterations each"
+                                   % (n, args.iters),
+                       "pairs_per_gpu": npairs, "points": n, "iters": args.iters,
+                       "sharding": "scan pairs one batch per GPU; pose all-gather over RCCL"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "icp_step_kernel", "avg_launch_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": abytes},
+            "index_build_s": build_s,
+            "value_incl_build": total_pairs * args.iters * args.steps / (dt + build_s * args.steps),
+            "single_pair_iters_per_s": single,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, args.iters)
+    sb.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,284 @@
+"""Python host mirror of include/gpscal.h.
+
+Every array argument may be a numpy array (host memory) or a torch CUDA tensor
+(device memory, used in place by the kernels): the C ABI takes plain pointers and
+asks the HIP runtime which side they live on.  PyTorch is plumbing only.
+
+Names follow the reference's interface for the path:
+  Context.weights_speed / weights_irls   <- WeightCoeCal::ICPWeightCoeCal (weight_calculation.h:14-16)
+  Context.track_fit                      <- trackCalibration(...), doICP(), doCalibration() (track_calibration.h:12-23)
+  Context.long_segment                   <- longDisTrackPro body (long_distance_track_process.cpp:58-83)
+  Context.wgs_to_enu / enu_to_wgs / gps_to_enu <- GPSPro (gps_process.h:53-56, 73-76)
+  KnnIndex.search                        <- pcl::KdTreeFLANN::nearestKSearch (laserOdometry.cpp:603, laserMapping.cpp:760)
+  ScanBatch.icp                          <- the generic scan-matching iteration
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import GpscalError, load
+
+METHOD = {"UTM": 0, "Gaussion": 1, "Gauss": 1, 0: 0, 1: 1}
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if _is_torch(x):
+        assert x.is_contiguous()
+        return C.c_void_p(x.data_ptr())
+    assert x.flags["C_CONTIGUOUS"]
+    return C.c_void_p(x.ctypes.data)
+
+
+def _f64(x):
+    if x is None or _is_torch(x):
+        return x
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def _f32(x):
+    if x is None or _is_torch(x):
+        return x
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+class Context:
+    """One GPU, one HIP stream (gpscal_ctx).  Fails loudly without a gfx950 device."""
+
+    def __init__(self, device_id=0):
+        self._L = load()
+        h = C.c_void_p()
+        rc = self._L.gpscal_create(C.byref(h), int(device_id), 0)
+        if rc:
+            raise GpscalError(rc, "gpscal_create(device %d)" % device_id)
+        self._h = h
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gpscal_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _ck(self, rc, what):
+        if rc:
+            raise GpscalError(rc, "%s: %s" % (what, self._L.gpscal_last_error(self._h).decode()))
+
+    def sync(self):
+        self._ck(self._L.gpscal_sync(self._h), "gpscal_sync")
+
+    @property
+    def stream(self):
+        return self._L.gpscal_stream(self._h)
+
+    def info(self):
+        buf = C.create_string_buffer(256)
+        self._L.gpscal_device_info(self._h, buf, 256)
+        return buf.value.decode()
+
+    # ------------------------------------------------------------ weights
+    def weights_speed(self, slam_xyzt):
+        s = _f64(slam_xyzt)
+        n = len(s)
+        w = np.empty(n)
+        self._ck(self._L.gpscal_weights_speed(self._h, _ptr(s), n, _ptr(w)), "weights_speed")
+        return w
+
+    def weights_irls(self, slam_xyzt, enu_xyzt, fit_xyzt):
+        s, e, f = _f64(slam_xyzt), _f64(enu_xyzt), _f64(fit_xyzt)
+        n = len(s)
+        if len(e) != n or len(f) != n:
+            raise GpscalError(-5, "weights_irls: sizes differ")
+        w = np.empty(n)
+        self._ck(self._L.gpscal_weights_irls(self._h, _ptr(s), _ptr(e), _ptr(f), n, _ptr(w)), "weights_irls")
+        return w
+
+    # -------------------------------------------------------------- track
+    def track_fit(self, slam_xyzt, enu_xyzt, w, seg_offsets=None):
+        """Returns (T, rotated_xyz, calibrated_xyzt).  With seg_offsets, T is (nseg,4,4)."""
+        s, e, w = _f64(slam_xyzt), _f64(enu_xyzt), _f64(w)
+        n = len(s)
+        if len(e) != n or len(w) != n:  # the reference exit(1)s here (track_calibration.cc:46-50)
+            raise GpscalError(-5, "track_fit: SLAM/ENU/weight sizes differ")
+        rot = np.empty((n, 3))
+        cal = np.empty((n, 4))
+        if seg_offsets is None:
+            T = np.empty((4, 4))
+            self._ck(self._L.gpscal_track_fit(self._h, _ptr(s), _ptr(e), _ptr(w), n, _ptr(T), _ptr(rot), _ptr(cal)),
+                     "track_fit")
+        else:
+            so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+            nseg = len(so) - 1
+            T = np.empty((nseg, 4, 4))
+            self._ck(self._L.gpscal_track_fit_batched(self._h, _ptr(s), _ptr(e), _ptr(w), _ptr(so), nseg, _ptr(T),
+                                                      _ptr(rot), _ptr(cal)), "track_fit_batched")
+        return T, rot, cal
+
+    def long_segment(self, slam_xyzt, enu_xyzt, irls_iters=5, seg_offsets=None):
+        """Returns (w_final, last_fit_xyzt)."""
+        s, e = _f64(slam_xyzt), _f64(enu_xyzt)
+        n = len(s)
+        if len(e) != n:
+            raise GpscalError(-5, "long_segment: SLAM/ENU sizes differ")
+        w = np.empty(n)
+        fit = np.empty((n, 4))
+        if seg_offsets is None:
+            self._ck(self._L.gpscal_long_segment(self._h, _ptr(s), _ptr(e), n, irls_iters, _ptr(w), _ptr(fit)),
+                     "long_segment")
+        else:
+            so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+            self._ck(self._L.gpscal_long_segment_batched(self._h, _ptr(s), _ptr(e), _ptr(so), len(so) - 1,
+                                                         irls_iters, _ptr(w), _ptr(fit)), "long_segment_batched")
+        return w, fit
+
+    # ---------------------------------------------------------------- geo
+    def wgs_to_enu(self, lat, lon, method="UTM", band_type=3):
+        lat, lon = _f64(lat), _f64(lon)
+        xy = np.empty((len(lat), 2))
+        self._ck(self._L.gpscal_wgs_to_enu(self._h, METHOD[method], band_type, _ptr(lat), _ptr(lon), len(lat),
+                                           _ptr(xy)), "wgs_to_enu")
+        return xy
+
+    def enu_to_wgs(self, enu_xyztw, method="UTM", band_type=3):
+        e = _f64(enu_xyztw)
+        ll = np.empty((len(e), 2))
+        alt = np.empty(len(e))
+        self._ck(self._L.gpscal_enu_to_wgs(self._h, METHOD[method], band_type, _ptr(e), len(e), _ptr(ll), _ptr(alt)),
+                 "enu_to_wgs")
+        return ll, alt
+
+    def gps_to_enu(self, lat, lon, gps_t, slam_xyzt, method="UTM", band_type=3):
+        lat, lon, gt, s = _f64(lat), _f64(lon), _f64(gps_t), _f64(slam_xyzt)
+        enu = np.empty((len(s), 4))
+        k = C.c_int(0)
+        self._ck(self._L.gpscal_gps_to_enu(self._h, METHOD[method], band_type, _ptr(lat), _ptr(lon), _ptr(gt),
+                                           len(gt), _ptr(s), len(s), _ptr(enu), C.byref(k)), "gps_to_enu")
+        return enu[:k.value].copy()
+
+    def height_compensate(self, loam_xyzt):
+        p = _f64(loam_xyzt)
+        out = np.empty((len(p), 4))
+        self._ck(self._L.gpscal_height_compensate(self._h, _ptr(p), len(p), _ptr(out)), "height_compensate")
+        return out
+
+    # ------------------------------------------------------------ factories
+    def knn_index(self, xyz, stride_bytes=12, cell_size=0.0):
+        return KnnIndex(self, xyz, stride_bytes, cell_size)
+
+    def scan_batch(self, tgt_xyz, tgt_off, src_xyz, src_off, w=None, cell_size=0.0):
+        return ScanBatch(self, tgt_xyz, tgt_off, src_xyz, src_off, w, cell_size)
+
+
+class KnnIndex:
+    """Exact k-NN index over one cloud (gpscal_knn_build / _search / _free)."""
+
+    def __init__(self, ctx, xyz, stride_bytes=12, cell_size=0.0):
+        self.ctx = ctx
+        self._xyz = _f32(xyz)
+        if _is_torch(self._xyz):
+            m = self._xyz.numel() * self._xyz.element_size() // stride_bytes
+        else:
+            m = self._xyz.size * 4 // stride_bytes
+        self.m = m
+        h = C.c_void_p()
+        ctx._ck(ctx._L.gpscal_knn_build(ctx._h, _ptr(self._xyz), m, stride_bytes, C.c_float(cell_size), C.byref(h)),
+                "knn_build")
+        self._h = h
+
+    def search(self, query_xyz, k=1, stride_bytes=12, out_idx=None, out_sqd=None):
+        q = _f32(query_xyz)
+        n = (q.numel() * q.element_size() if _is_torch(q) else q.size * 4) // stride_bytes
+        idx = out_idx if out_idx is not None else np.empty((n, k), dtype=np.int32)
+        sqd = out_sqd if out_sqd is not None else np.empty((n, k), dtype=np.float32)
+        self.ctx._ck(self.ctx._L.gpscal_knn_search(self._h, _ptr(q), n, stride_bytes, k, _ptr(idx), _ptr(sqd)),
+                     "knn_search")
+        return idx, sqd
+
+    def icp_run(self, src_xyz, iters, T0=None, w=None, stride_bytes=12):
+        s = _f32(src_xyz)
+        n = (s.numel() * s.element_size() if _is_torch(s) else s.size * 4) // stride_bytes
+        T0 = None if T0 is None else _f64(np.asarray(T0).reshape(16))
+        w = _f64(w)
+        T = np.empty((4, 4))
+        hist = np.empty(max(iters, 1))
+        self.ctx._ck(self.ctx._L.gpscal_icp_run(self.ctx._h, self._h, _ptr(s), n, stride_bytes, _ptr(w), iters,
+                                                _ptr(T0), _ptr(T), _ptr(hist)), "icp_run")
+        return T, hist[:iters]
+
+    def icp_iterate(self, src_xyz, T_in, w=None, stride_bytes=12):
+        T, hist = self.icp_run(src_xyz, 1, T_in, w, stride_bytes)
+        return T, float(hist[0])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._L.gpscal_knn_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class ScanBatch:
+    """npairs independent (target, source) scan pairs resident in HBM."""
+
+    def __init__(self, ctx, tgt_xyz, tgt_off, src_xyz, src_off, w=None, cell_size=0.0):
+        self.ctx = ctx
+        self._keep = (_f32(tgt_xyz), _f32(src_xyz), _f64(w))
+        to = np.ascontiguousarray(tgt_off, dtype=np.int64)
+        so = np.ascontiguousarray(src_off, dtype=np.int64)
+        self.npairs = len(to) - 1
+        self.n_total = int(so[-1] - so[0])
+        self.m_total = int(to[-1] - to[0])
+        h = C.c_void_p()
+        ctx._ck(ctx._L.gpscal_scan_batch_create(ctx._h, self.npairs, _ptr(self._keep[0]), _ptr(to),
+                                                _ptr(self._keep[1]), _ptr(so), _ptr(self._keep[2]),
+                                                C.c_float(cell_size), C.byref(h)), "scan_batch_create")
+        self._h = h
+
+    def set_pose(self, T0=None):
+        T0 = None if T0 is None else _f64(np.asarray(T0).reshape(self.npairs, 16))
+        self.ctx._ck(self.ctx._L.gpscal_scan_batch_set_pose(self._h, _ptr(T0)), "scan_batch_set_pose")
+
+    def icp(self, iters, want_err=True, profile=False, T_out=None):
+        """Runs `iters` iterations.  Returns (T[npairs,4,4], mean_err[npairs,iters] | None, step_ms | None)."""
+        T = T_out if T_out is not None else np.empty((self.npairs, 4, 4))
+        err = np.empty((self.npairs, iters)) if want_err else None
+        ms = np.empty(iters, dtype=np.float32) if profile else None
+        self.ctx._ck(self.ctx._L.gpscal_scan_batch_icp(self._h, iters, _ptr(T), _ptr(err), _ptr(ms)),
+                     "scan_batch_icp")
+        return T, err, ms
+
+    def correspondences(self):
+        idx = np.empty(self.n_total, dtype=np.int32)
+        sqd = np.empty(self.n_total, dtype=np.float32)
+        self.ctx._ck(self.ctx._L.gpscal_scan_batch_correspondences(self._h, _ptr(idx), _ptr(sqd)),
+                     "scan_batch_correspondences")
+        return idx, sqd
+
+    @property
+    def build_seconds(self):
+        return self.ctx._L.gpscal_scan_batch_build_seconds(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._L.gpscal_scan_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

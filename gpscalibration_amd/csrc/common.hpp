@@ -1,0 +1,144 @@
+// common.hpp -- context, error plumbing and host<->HBM argument staging shared by
+// every translation unit of libgpscal_hip.so.  gfx950 only; no CPU fallback.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gpscal.h"
+
+struct gpscal_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+    std::string last_error;
+    void *comm = nullptr;  // ncclComm_t, owned by comm.hip
+    int rank = 0, world = 1;
+};
+
+namespace gpscal {
+
+inline int fail(gpscal_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        char buf[512];
+        if (e != hipSuccess)
+            snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        else
+            snprintf(buf, sizeof buf, "%s", what);
+        ctx->last_error = buf;
+    }
+    return code;
+}
+
+#define GPSCAL_HIP(ctx, expr)                                                    \
+    do {                                                                         \
+        hipError_t e__ = (expr);                                                 \
+        if (e__ != hipSuccess) return ::gpscal::fail((ctx), GPSCAL_EHIP, #expr, e__); \
+    } while (0)
+
+// True when ptr addresses device (HBM) memory the kernels can use in place.
+inline bool is_device_ptr(const void *ptr)
+{
+    if (!ptr) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc memory: not an error for us
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count)
+    {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+};
+
+// Read-only argument: device pointers pass through, host pointers are staged.
+template <class T>
+struct InArg {
+    const T *dev = nullptr;
+    DevBuf<T> tmp;
+    hipError_t bind(gpscal_ctx *ctx, const T *ptr, size_t count)
+    {
+        if (!ptr || count == 0) {
+            dev = nullptr;
+            return hipSuccess;
+        }
+        if (is_device_ptr(ptr)) {
+            dev = ptr;
+            return hipSuccess;
+        }
+        hipError_t e = tmp.alloc(count);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(tmp.p, ptr, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+        dev = tmp.p;
+        return e;
+    }
+};
+
+// Output argument: device pointers are written in place; host pointers get a
+// device scratch buffer that commit() copies back (caller then syncs).
+template <class T>
+struct OutArg {
+    T *dev = nullptr;
+    T *host = nullptr;
+    size_t count = 0;
+    DevBuf<T> tmp;
+    hipError_t bind(gpscal_ctx *, T *ptr, size_t cnt)
+    {
+        count = cnt;
+        if (!ptr || cnt == 0) {
+            dev = nullptr;
+            host = nullptr;
+            return hipSuccess;
+        }
+        if (is_device_ptr(ptr)) {
+            dev = ptr;
+            return hipSuccess;
+        }
+        host = ptr;
+        hipError_t e = tmp.alloc(cnt);
+        dev = tmp.p;
+        return e;
+    }
+    // returns true when a host copy was enqueued (caller must sync the stream)
+    hipError_t commit(gpscal_ctx *ctx, bool *needs_sync, size_t cnt_override = (size_t)-1)
+    {
+        if (!host) return hipSuccess;
+        size_t c = cnt_override == (size_t)-1 ? count : cnt_override;
+        *needs_sync = true;
+        if (c == 0) return hipSuccess;
+        return hipMemcpyAsync(host, dev, c * sizeof(T), hipMemcpyDeviceToHost, ctx->stream);
+    }
+};
+
+inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace gpscal

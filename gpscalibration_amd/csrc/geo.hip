@@ -1,0 +1,293 @@
+// geo.hip -- WGS84 <-> local projection (UTM / Gauss-Krueger as coded by the
+// reference) and GPS-at-SLAM-stamp interpolation, one lane per sample, float64.
+// gfx950 only.
+//
+// Replaces (under /root/reference/src/gpsCalibration/src/gps_calibration/):
+//   GPSPro::UTMTransform            gps_process.cc:851-908
+//   GPSPro::GaussionTransform       gps_process.cc:953-1007 (+ arcLength :38-56)
+//   GPSPro::UTMReverseTransform     gps_process.cc:1010-1058
+//   GPSPro::GaussionReverseTransform gps_process.cc:911-950
+//   GPSPro::interPolate             gps_process.cc:59-110
+//   tail of GPSPro::GPSToENU        gps_process.cc:498-518
+// Reference quirks kept: PI = 3.141592653589 (common.h:17); WGS84 b = 6356752.314
+// (gps_process.cc:1114); UTM northing's A^6 term outside N*tan (gps_process.cc:899);
+// band number from the first fix only (gps_process.cc:869-877).
+#include "common.hpp"
+
+namespace gpscal {
+
+constexpr double REF_PI = 3.141592653589;
+constexpr double WGS_A = 6378137.0;
+constexpr double WGS_B = 6356752.314;
+
+struct Ellipsoid {
+    double e1, e2, c;  // WGSParameter::E1, E2, C (gps_process.cc:1115-1117)
+};
+__host__ __device__ inline Ellipsoid ellipsoid()
+{
+    Ellipsoid e;
+    double d = sqrt(WGS_A * WGS_A - WGS_B * WGS_B);
+    e.e1 = d / WGS_A;
+    e.e2 = d / WGS_B;
+    e.c = WGS_A * WGS_A / WGS_B;
+    return e;
+}
+
+__device__ __forceinline__ int band_of(double lon, int band_type)
+{
+    if (band_type == 3) {
+        int band = (int)(lon / 3);
+        double tmp = lon / 3;
+        if (tmp - band > 0.5) band += 1;
+        return band;
+    }
+    return (int)lon / 6 + 1;
+}
+
+// "if (0 == bandNum)" re-evaluates the band until it becomes non-zero
+// (gps_process.cc:869-877): band of sample i = first non-zero band among 0..i.
+__device__ __forceinline__ int sticky_band(const double *lon, int i, int band_type)
+{
+    int b = band_of(lon[0], band_type);
+    for (int j = 1; b == 0 && j <= i; ++j) b = band_of(lon[j], band_type);
+    return b;
+}
+
+__device__ __forceinline__ double pw2(double x) { return x * x; }
+__device__ __forceinline__ double pw3(double x) { return x * x * x; }
+__device__ __forceinline__ double pw4(double x) { double y = x * x; return y * y; }
+__device__ __forceinline__ double pw5(double x) { double y = x * x; return y * y * x; }
+__device__ __forceinline__ double pw6(double x) { double y = x * x; return y * y * y; }
+
+__device__ inline double arc_length(double latitude, const Ellipsoid &el)
+{
+    double e1s = pw2(el.e1);
+    double m0 = WGS_A * (1 - e1s);
+    double m2 = 3.0 / 2.0 * e1s * m0;
+    double m4 = 5.0 / 4.0 * e1s * m2;
+    double m6 = 7.0 / 6.0 * e1s * m4;
+    double m8 = 9.0 / 8.0 * e1s * m6;
+    double a0 = m0 + 1.0 / 2.0 * m2 + 3.0 / 8.0 * m4 + 5.0 / 16.0 * m6 + 35.0 / 128.0 * m8;
+    double a2 = 1.0 / 2.0 * m2 + 1.0 / 2.0 * m4 + 15.0 / 32.0 * m6 + 7.0 / 16.0 * m8;
+    double a4 = 1.0 / 8.0 * m4 + 3.0 / 16.0 * m6 + 7.0 / 32.0 * m8;
+    double a6 = 1.0 / 32.0 * m6 + 1.0 / 16.0 * m8;
+    double a8 = 1.0 / 128.0 * m8;
+    double rB = latitude * REF_PI / 180.0;
+    return a0 * rB - a2 / 2.0 * sin(2 * rB) + a4 / 4.0 * sin(4 * rB) - a6 / 6.0 * sin(6 * rB) +
+           a8 / 8.0 * sin(8 * rB);
+}
+
+__device__ inline void project_fwd(int method, int band_type, int band, double lat, double lon, double &x, double &y)
+{
+    const Ellipsoid el = ellipsoid();
+    double meridian = band_type == 3 ? 3.0 * band : (double)(6 * band - 3);
+    double rB = lat * REF_PI / 180.0;
+    if (method == GPSCAL_METHOD_UTM) {
+        const double k0 = 0.9996;
+        double tn = tan(rB), cs = cos(rB), sn = sin(rB);
+        double t = tn * tn;
+        double c = pw2(el.e2) * pw2(cs);
+        double A = (lon - meridian) * REF_PI / 180.0 * cs;
+        double N = WGS_A / sqrt(1 - el.e1 * el.e1 * sn * sn);
+        double e12 = pw2(el.e1), e14 = pw4(el.e1), e16 = pw6(el.e1);
+        double M = WGS_A * ((1 - e12 / 4.0 - 3.0 * e14 / 64.0 - 5.0 * e16 / 256.0) * rB -
+                            (3.0 * e12 / 8.0 + 3.0 * e14 / 32.0 + 45.0 * e16 / 1024.0) * sin(2 * rB) +
+                            (15.0 * e14 / 256.0 + 45.0 * e16 / 1024.0) * sin(4 * rB) -
+                            35.0 * e16 / 3072.0 * sin(6 * rB));
+        x = k0 * (M + N * tn * (A * A / 2.0 + (5 - t + 9 * c + 4 * c * c) * pw4(A) / 24.0) +
+                  (61 - 58 * t + t * t + 600 * c - 330 * el.e2 * el.e2) * pw6(A) / 720.0);
+        y = k0 * N * (A + (1 - t + c) * pw3(A) / 6.0 +
+                      (5 - 18 * t + t * t + 72 * c - 58 * el.e2 * el.e2) * pw5(A) / 120.0) +
+            500000;
+    } else {
+        double t = tan(rB), cs = cos(rB);
+        double ng2 = pw2(el.e2) * pw2(cs);
+        double N = el.c / sqrt(1 + ng2);
+        double m = cs * REF_PI / 180.0 * (lon - meridian);
+        double ml = arc_length(lat, el);
+        x = ml + N * t * (1.0 / 2.0 * m * m + 1.0 / 24.0 * (5 - t * t + 9 * ng2 + 4 * ng2 * ng2) * pw4(m) +
+                          1.0 / 720.0 * (61 - 58 * t * t + pw4(t) + 270 * ng2 - 330 * ng2 * t * t) * pw6(m));
+        y = N * (m + 1.0 / 6.0 * (1 - t * t + ng2) * pw3(m) +
+                 1.0 / 120.0 * (5 - 18 * t * t + pw4(t) + 14 * ng2 - 58 * ng2 * t * t) * pw5(m)) +
+            500000;
+    }
+    y += (double)band * 10000000;
+}
+
+__global__ void wgs_to_enu_kernel(int method, int band_type, const double *__restrict__ lat,
+                                  const double *__restrict__ lon, int n, double *__restrict__ xy)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int band = sticky_band(lon, i, band_type);
+    double x, y;
+    project_fwd(method, band_type, band, lat[i], lon[i], x, y);
+    xy[2 * (size_t)i] = x;
+    xy[2 * (size_t)i + 1] = y;
+}
+
+__global__ void enu_to_wgs_kernel(int method, int band_type, const double *__restrict__ enu, int n,
+                                  double *__restrict__ lonlat, double *__restrict__ alt)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Ellipsoid el = ellipsoid();
+    double ex = enu[5 * (size_t)i], ey = enu[5 * (size_t)i + 1];
+    int band = (int)(ey / 10000000);
+    double meridian = band_type == 3 ? 3.0 * band : (double)(6 * band - 3);
+    double ly = ey - (double)band * 10000000 - 500000;
+    const double k0 = method == GPSCAL_METHOD_UTM ? 0.9996 : 1.0;
+    double X = method == GPSCAL_METHOD_UTM ? ex / k0 : ex;
+    double e12 = pw2(el.e1), e14 = pw4(el.e1), e16 = pw6(el.e1);
+    double fi = X / (WGS_A * (1 - e12 / 4 - 3 * e14 / 64 - 5 * e16 / 256));
+    double e = (1 - WGS_B / WGS_A) / (1 + WGS_B / WGS_A);
+    double Bf = fi + (3 * e / 2 - 27 * pw3(e) / 32) * sin(2 * fi) + (21 * e * e / 16 - 55 * pw4(e) / 32) * sin(4 * fi) +
+                151 * pw3(e) / 96 * sin(6 * fi);
+    double sB = sin(Bf), cB = cos(Bf), tB = tan(Bf);
+    double q = 1 - el.e1 * el.e1 * sB * sB;
+    double Nf = WGS_A / sqrt(q);
+    double Rf = WGS_A * (1 - el.e1 * el.e1) / (q * sqrt(q));
+    double Cf = el.e2 * el.e2 * cB * cB;
+    double Tf = tB * tB;
+    double latitude, longitude;
+    if (method == GPSCAL_METHOD_UTM) {
+        double D = ly / (k0 * Nf);
+        latitude = Bf - Nf * tB / Rf *
+                            (D * D / 2 - (5 + 3 * Tf + 10 * Cf - 4 * Cf * Cf - 9 * el.e2 * el.e2) * pw4(D) / 24.0 +
+                             (61 + 90 * Tf + 298 * Cf + 45 * Tf * Tf - 252 * el.e2 * el.e2 - 3 * Cf * Cf) * pw6(D) / 720);
+        longitude = meridian + (1.0 / cB *
+                                (D - (1 + 2 * Tf + Cf) * pw3(D) / 6.0 +
+                                 (5 - 2 * Cf + 28 * Tf - 3 * Cf * Cf + 8 * el.e2 * el.e2 + 24 * Tf * Tf) * pw5(D) / 120.0)) *
+                                   180 / REF_PI;
+    } else {
+        double D = ly / Nf;
+        latitude = Bf - Nf * tB / Rf *
+                            (D * D / 2 - (5 + 3 * Tf + Cf - 9 * Tf * Cf) * pw4(D) / 24 +
+                             (61 + 90 * Tf + 45 * Tf * Tf) * pw6(D) / 720);
+        longitude = meridian + (1.0 / cB *
+                                (D - (1 + 2 * Tf + Cf) * pw3(D) / 6 +
+                                 (5 + 28 * Tf + 6 * Cf + 8 * Tf * Cf + 24 * Tf * Tf) * pw5(D) / 120)) *
+                                   180 / REF_PI;
+    }
+    latitude = latitude * 180 / REF_PI;
+    lonlat[2 * (size_t)i] = longitude;  // gps_process.cc:1053: (lon, lat)
+    lonlat[2 * (size_t)i + 1] = latitude;
+    alt[i] = enu[5 * (size_t)i + 2];
+}
+
+// interPolate (gps_process.cc:85-107) for time-ordered logs: stamp r belongs to
+// the first interval s with slam_t[r] <= gps_t[s+1]; stamps past the last fix
+// are dropped (counted through *n_kept).  Output rows gps_process.cc:510-518.
+__global__ void interp_kernel(const double *__restrict__ xy, const double *__restrict__ gt, int ngps,
+                              const double *__restrict__ slam, int nslam, double *__restrict__ enu,
+                              int *__restrict__ n_kept)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nslam) return;
+    double tr = slam[4 * (size_t)r + 3];
+    if (ngps < 2 || tr > gt[ngps - 1]) return;  // dropped (gps_process.cc:99)
+    int lo = 0, hi = ngps - 2;                  // smallest s with gt[s+1] >= tr
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (gt[mid + 1] >= tr) hi = mid; else lo = mid + 1;
+    }
+    int s = lo;
+    double s1 = gt[s], s2 = gt[s + 1], s3 = s2 - s1;
+    double c1 = (tr - s1) / s3, c2 = 1.0 - c1;
+    enu[4 * (size_t)r + 0] = c1 * xy[2 * (size_t)(s + 1)] + c2 * xy[2 * (size_t)s];
+    enu[4 * (size_t)r + 1] = c1 * xy[2 * (size_t)(s + 1) + 1] + c2 * xy[2 * (size_t)s + 1];
+    enu[4 * (size_t)r + 2] = slam[4 * (size_t)r + 2];
+    enu[4 * (size_t)r + 3] = tr;
+    atomicAdd(n_kept, 1);
+}
+
+}  // namespace gpscal
+
+using namespace gpscal;
+
+static int check_proj(gpscal_ctx *ctx, int method, int band_type)
+{
+    if (!ctx) return GPSCAL_EINVAL;
+    if (method != GPSCAL_METHOD_UTM && method != GPSCAL_METHOD_GAUSS)
+        return fail(ctx, GPSCAL_EINVAL, "method must be GPSCAL_METHOD_UTM or GPSCAL_METHOD_GAUSS");
+    if (band_type != 3 && band_type != 6) return fail(ctx, GPSCAL_EINVAL, "band_type must be 3 or 6");
+    return GPSCAL_OK;
+}
+
+extern "C" int gpscal_wgs_to_enu(gpscal_ctx *ctx, int method, int band_type, const double *lat, const double *lon,
+                                 int n, double *xy)
+{
+    int rc = check_proj(ctx, method, band_type);
+    if (rc) return rc;
+    if (!lat || !lon || !xy || n < 1) return fail(ctx, GPSCAL_EINVAL, "gpscal_wgs_to_enu: bad argument");
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    InArg<double> a, b;
+    OutArg<double> o;
+    GPSCAL_HIP(ctx, a.bind(ctx, lat, n));
+    GPSCAL_HIP(ctx, b.bind(ctx, lon, n));
+    GPSCAL_HIP(ctx, o.bind(ctx, xy, (size_t)n * 2));
+    hipLaunchKernelGGL(wgs_to_enu_kernel, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, method, band_type, a.dev,
+                       b.dev, n, o.dev);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    bool sync = true;
+    GPSCAL_HIP(ctx, o.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}
+
+extern "C" int gpscal_enu_to_wgs(gpscal_ctx *ctx, int method, int band_type, const double *enu, int n, double *lonlat,
+                                 double *alt)
+{
+    int rc = check_proj(ctx, method, band_type);
+    if (rc) return rc;
+    if (!enu || !lonlat || !alt || n < 1) return fail(ctx, GPSCAL_EINVAL, "gpscal_enu_to_wgs: bad argument");
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    InArg<double> a;
+    OutArg<double> o1, o2;
+    GPSCAL_HIP(ctx, a.bind(ctx, enu, (size_t)n * 5));
+    GPSCAL_HIP(ctx, o1.bind(ctx, lonlat, (size_t)n * 2));
+    GPSCAL_HIP(ctx, o2.bind(ctx, alt, n));
+    hipLaunchKernelGGL(enu_to_wgs_kernel, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, method, band_type, a.dev, n,
+                       o1.dev, o2.dev);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    bool sync = true;
+    GPSCAL_HIP(ctx, o1.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, o2.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}
+
+extern "C" int gpscal_gps_to_enu(gpscal_ctx *ctx, int method, int band_type, const double *lat, const double *lon,
+                                 const double *gps_t, int ngps, const double *slam, int nslam, double *enu, int *n_out)
+{
+    int rc = check_proj(ctx, method, band_type);
+    if (rc) return rc;
+    if (!lat || !lon || !gps_t || !slam || !enu || !n_out || ngps < 1 || nslam < 1)
+        return fail(ctx, GPSCAL_EINVAL, "gpscal_gps_to_enu: bad argument");
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    InArg<double> a, b, t, s;
+    OutArg<double> o;
+    DevBuf<double> xy;
+    DevBuf<int> kept;
+    GPSCAL_HIP(ctx, a.bind(ctx, lat, ngps));
+    GPSCAL_HIP(ctx, b.bind(ctx, lon, ngps));
+    GPSCAL_HIP(ctx, t.bind(ctx, gps_t, ngps));
+    GPSCAL_HIP(ctx, s.bind(ctx, slam, (size_t)nslam * 4));
+    GPSCAL_HIP(ctx, o.bind(ctx, enu, (size_t)nslam * 4));
+    GPSCAL_HIP(ctx, xy.alloc((size_t)ngps * 2));
+    GPSCAL_HIP(ctx, kept.alloc(1));
+    GPSCAL_HIP(ctx, hipMemsetAsync(kept.p, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(wgs_to_enu_kernel, dim3(div_up(ngps, 256)), dim3(256), 0, ctx->stream, method, band_type,
+                       a.dev, b.dev, ngps, xy.p);
+    hipLaunchKernelGGL(interp_kernel, dim3(div_up(nslam, 256)), dim3(256), 0, ctx->stream, xy.p, t.dev, ngps, s.dev,
+                       nslam, o.dev, kept.p);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    int k = 0;
+    GPSCAL_HIP(ctx, hipMemcpyAsync(&k, kept.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    bool sync = false;
+    GPSCAL_HIP(ctx, o.commit(ctx, &sync, (size_t)k * 4));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = k;
+    return GPSCAL_OK;
+}

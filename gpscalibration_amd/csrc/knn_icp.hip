@@ -1,0 +1,1116 @@
+// knn_icp.hip -- exact k-NN over a multi-level uniform grid and the fused ICP
+// iteration (transform -> 1-NN -> weighted centroid/covariance partials) plus
+// the per-pair solve (partials -> 3x3 SVD -> pose update).  gfx950 only.
+//
+// Replaces pcl::KdTreeFLANN::setInputCloud / nearestKSearch (laserOdometry.cpp:
+// 538-539,603,758,1119-1120; laserMapping.cpp:750-751,760,867) and the
+// correspondence + BFTWithWeight loop of track_calibration.cc:145-181,366-545
+// generalised to 3-D point clouds.
+//
+// Data layout in HBM (per batch of scan pairs):
+//   tgt4        float4[sum m]            xyz + index-in-pair, caller order
+//   sorted      float4[sum m * L]        per (pair, level): points grouped by cell,
+//                                        cell id = (z*ny + y)*nx + x (x fastest, so
+//                                        the 3 x-neighbours of a row are ONE run)
+//   cell_start  uint32[total cells + 1]  global exclusive scan of the cell counts
+//                                        = absolute position of each cell in `sorted`
+//   src4        float4[sum n]            sources grouped by their own level-0 cell
+//                                        (rigid motion keeps that order coherent)
+//   nn_idx/sqd  int32/float[sum n]       correspondences, in src4 order
+//   partials    double[blocks][NACC]     per-block sums, reduced in fixed order
+//   pose        double[pairs][16] + float[pairs][12]
+// Roofline: HBM; algorithmic bytes per iteration = 20 n + 12 m.
+#include "common.hpp"
+#include "svd3.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+namespace gpscal {
+
+constexpr int MAX_LEVELS = 6;
+constexpr int BLOCK = 256;
+constexpr int NACC_PLAIN = 17;   // n, sum p(3), sum q(3), sum p q^T(9), sum dist
+constexpr int NACC_WEIGHTED = 25;  // + sw, sw2, sum w2 p(3), sum w2 q(3) (w-sums replace n)
+
+struct GridDesc {
+    float ox, oy, oz, inv_h;
+    float h, margin;
+    int nx, ny, nz;
+    int pad;
+    long long cell_base;
+};
+
+struct PairDesc {
+    long long tgt_off;  // into tgt4
+    long long src_off;  // into src4 / nn arrays / weights
+    int m, n;
+    int nlevels;
+    int pblk_off;  // first partial slot of this pair
+    int pblk_cnt;
+    int pad;
+    GridDesc lv[MAX_LEVELS];
+};
+
+// ------------------------------------------------------------------ helpers
+
+__device__ __forceinline__ int f2ord(float f)
+{
+    int b = __float_as_int(f);
+    return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__host__ __device__ __forceinline__ float ord2f(int k)
+{
+    int b = k >= 0 ? k : k ^ 0x7fffffff;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __int_as_float(b);
+#else
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+#endif
+}
+__device__ __forceinline__ bool finite3(float x, float y, float z)
+{
+    return isfinite(x) && isfinite(y) && isfinite(z);
+}
+
+// The squared distance every implementation shares (oracle: orc_sqdist).
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz)
+{
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+}
+
+// XCD-aware block remap (cdna_hip_programming.md T1, bijective form): logical
+// blocks that are adjacent in memory land on the same XCD, i.e. the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk)
+{
+    int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// --------------------------------------------------------------- build path
+
+__global__ void pack_points_kernel(const char *__restrict__ raw, int stride, const long long *__restrict__ offs,
+                                   int npairs, long long total, float4 *__restrict__ out)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    // pair of point i: last b with offs[b] <= i
+    int lo = 0, hi = npairs;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (offs[mid] <= i) lo = mid; else hi = mid;
+    }
+    const float *p = reinterpret_cast<const float *>(raw + (size_t)i * stride);
+    out[i] = make_float4(p[0], p[1], p[2], __int_as_float((int)(i - offs[lo])));
+}
+
+// bbox[pair][6] holds order-preserving int keys: min xyz then max xyz.
+__global__ void bbox_kernel(const float4 *__restrict__ pts, const long long *__restrict__ offs,
+                            int *__restrict__ bbox)
+{
+    int b = blockIdx.y;
+    long long o = offs[b];
+    int m = (int)(offs[b + 1] - o);
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        float4 p = pts[o + i];
+        if (!finite3(p.x, p.y, p.z)) continue;
+        mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+        mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+        mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], s));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], s));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&bbox[b * 6 + a], f2ord(mn[a]));
+            atomicMax(&bbox[b * 6 + 3 + a], f2ord(mx[a]));
+        }
+    }
+}
+
+__device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n)
+{
+    int c = (int)floorf((p - o) * inv_h);
+    return min(max(c, 0), n - 1);
+}
+
+__device__ __forceinline__ long long cell_of(const GridDesc &G, float x, float y, float z)
+{
+    int cx = cell_coord(x, G.ox, G.inv_h, G.nx);
+    int cy = cell_coord(y, G.oy, G.inv_h, G.ny);
+    int cz = cell_coord(z, G.oz, G.inv_h, G.nz);
+    return G.cell_base + ((long long)cz * G.ny + cy) * G.nx + cx;
+}
+
+// pass 0: count points per cell; pass 1: scatter into the sorted array.
+template <int PASS>
+__global__ void grid_fill_kernel(const PairDesc *__restrict__ pairs, const float4 *__restrict__ tgt4,
+                                 unsigned *__restrict__ counts, const unsigned *__restrict__ cell_start,
+                                 float4 *__restrict__ sorted)
+{
+    int b = blockIdx.y;
+    const PairDesc &P = pairs[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.m; i += gridDim.x * blockDim.x) {
+        float4 p = tgt4[P.tgt_off + i];
+        if (!finite3(p.x, p.y, p.z)) continue;
+        for (int l = 0; l < P.nlevels; ++l) {
+            long long c = cell_of(P.lv[l], p.x, p.y, p.z);
+            unsigned k = atomicAdd(&counts[c], 1u);
+            if (PASS == 1) sorted[cell_start[c] + k] = p;
+        }
+    }
+}
+
+// ---- exclusive scan (uint32), 2048 elements per block
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = BLOCK * SCAN_ITEMS;
+
+__global__ __launch_bounds__(BLOCK) void scan_tile_kernel(const unsigned *__restrict__ in,
+                                                           unsigned *__restrict__ out,
+                                                           unsigned *__restrict__ tile_sums, long long n)
+{
+    __shared__ unsigned wave_tot[BLOCK / 64];
+    long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    unsigned v[SCAN_ITEMS];
+    unsigned sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        sum += v[k];
+    }
+    // inclusive wave scan of the per-thread sums
+    unsigned inc = sum;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        unsigned t = __shfl_up(inc, s);
+        if (lane >= s) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    unsigned woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        unsigned t = wave_tot[w];
+        if (w < wave) woff += t;
+        total += t;
+    }
+    unsigned run = woff + inc - sum;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ void scan_add_kernel(unsigned *__restrict__ data, const unsigned *__restrict__ tile_off, long long n)
+{
+    long long i = (long long)blockIdx.x * SCAN_TILE + threadIdx.x;
+    unsigned add = tile_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k, i += BLOCK)
+        if (i < n) data[i] += add;
+}
+
+static int exclusive_scan(gpscal_ctx *ctx, const unsigned *in, unsigned *out, long long n)
+{
+    int tiles = div_up(n, SCAN_TILE);
+    DevBuf<unsigned> sums, sums_scanned;
+    GPSCAL_HIP(ctx, sums.alloc(tiles));
+    hipLaunchKernelGGL(scan_tile_kernel, dim3(tiles), dim3(BLOCK), 0, ctx->stream, in, out, sums.p, n);
+    if (tiles > 1) {
+        GPSCAL_HIP(ctx, sums_scanned.alloc(tiles));
+        int rc = exclusive_scan(ctx, sums.p, sums_scanned.p, tiles);
+        if (rc) return rc;
+        hipLaunchKernelGGL(scan_add_kernel, dim3(tiles), dim3(BLOCK), 0, ctx->stream, out, sums_scanned.p, n);
+    }
+    GPSCAL_HIP(ctx, hipGetLastError());
+    // temporaries are freed on return: hipFree synchronises the device first
+    return GPSCAL_OK;
+}
+
+// ------------------------------------------------------------- query path
+
+template <int K>
+struct Best {
+    float d[K];
+    int i[K];
+    unsigned pos;  // position of the best candidate in `sorted` (K == 1 use)
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            d[k] = INFINITY;
+            i[k] = 0x7fffffff;
+        }
+        pos = 0;
+    }
+    __device__ __forceinline__ float worst() const { return d[K - 1]; }
+    __device__ __forceinline__ void consider(float d2, int idx, unsigned p)
+    {
+        if (d2 < d[K - 1] || (d2 == d[K - 1] && idx < i[K - 1])) {
+            d[K - 1] = d2;
+            i[K - 1] = idx;
+            if (K == 1) pos = p;
+#pragma unroll
+            for (int s = K - 1; s > 0; --s) {
+                bool sw = d[s] < d[s - 1] || (d[s] == d[s - 1] && i[s] < i[s - 1]);
+                if (sw) {
+                    float td = d[s]; d[s] = d[s - 1]; d[s - 1] = td;
+                    int ti = i[s]; i[s] = i[s - 1]; i[s - 1] = ti;
+                }
+            }
+        }
+    }
+};
+
+template <int K>
+__device__ __forceinline__ void scan_run(Best<K> &B, const float4 *__restrict__ sorted, unsigned s, unsigned e,
+                                         float px, float py, float pz)
+{
+    for (unsigned j = s; j < e; ++j) {
+        float4 c = sorted[j];
+        B.consider(sqdist(px, py, pz, c.x, c.y, c.z), __float_as_int(c.w), j);
+    }
+}
+
+// Exact k-NN of (px,py,pz) in pair P.  Levels are visited fine -> coarse; a
+// level's 3x3x3 block of cells settles the query when the k-th best distance is
+// within the distance to the nearest face of the block that still has cells
+// behind it.  The coarsest level has <= 2 cells per axis, so it always settles.
+template <int K>
+__device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__restrict__ sorted,
+                                          const unsigned *__restrict__ cell_start, float px, float py, float pz,
+                                          Best<K> &B)
+{
+    B.init();
+    for (int l = 0; l < P.nlevels; ++l) {
+        const GridDesc &G = P.lv[l];
+        const float h = G.h, mg = G.margin;
+        int cx = cell_coord(px, G.ox, G.inv_h, G.nx);
+        int cy = cell_coord(py, G.oy, G.inv_h, G.ny);
+        int cz = cell_coord(pz, G.oz, G.inv_h, G.nz);
+        // distances from p to the faces of its own cell (may be < 0 when p was clamped)
+        float fy0 = py - (G.oy + cy * h), fy1 = (G.oy + (cy + 1) * h) - py;
+        float fz0 = pz - (G.oz + cz * h), fz1 = (G.oz + (cz + 1) * h) - pz;
+        float fx0 = px - (G.ox + cx * h), fx1 = (G.ox + (cx + 1) * h) - px;
+        int xlo = max(cx - 1, 0), xhi = min(cx + 1, G.nx - 1);
+#pragma unroll
+        for (int rz = 0; rz < 3; ++rz) {
+            int dz = rz == 0 ? 0 : (rz == 1 ? -1 : 1);
+            int zz = cz + dz;
+            if (zz < 0 || zz >= G.nz) continue;
+            float bz = dz == 0 ? 0.f : fmaxf((dz < 0 ? fz0 : fz1) - mg, 0.f);
+#pragma unroll
+            for (int ry = 0; ry < 3; ++ry) {
+                int dy = ry == 0 ? 0 : (ry == 1 ? -1 : 1);
+                int yy = cy + dy;
+                if (yy < 0 || yy >= G.ny) continue;
+                float by = dy == 0 ? 0.f : fmaxf((dy < 0 ? fy0 : fy1) - mg, 0.f);
+                float rb2 = by * by + bz * bz;
+                if (rb2 * 0.99999f > B.worst()) continue;  // row cannot hold a better point
+                long long row = G.cell_base + ((long long)zz * G.ny + yy) * G.nx;
+                unsigned s = cell_start[row + xlo];
+                unsigned e = cell_start[row + xhi + 1];
+                scan_run<K>(B, sorted, s, e, px, py, pz);
+            }
+        }
+        // guaranteed radius of this level
+        float g = INFINITY;
+        if (cx - 1 > 0) g = fminf(g, fx0 + h);
+        if (cx + 1 < G.nx - 1) g = fminf(g, fx1 + h);
+        if (cy - 1 > 0) g = fminf(g, fy0 + h);
+        if (cy + 1 < G.ny - 1) g = fminf(g, fy1 + h);
+        if (cz - 1 > 0) g = fminf(g, fz0 + h);
+        if (cz + 1 < G.nz - 1) g = fminf(g, fz1 + h);
+        g = fmaxf(g - mg, 0.f);
+        if (B.worst() <= g * g * 0.99999f || g == INFINITY) break;
+    }
+}
+
+// Stand-alone batched search (gpscal_knn_search): one lane per query.
+template <int K>
+__global__ __launch_bounds__(BLOCK) void knn_search_kernel(const PairDesc *__restrict__ pairs,
+                                                            const float4 *__restrict__ sorted,
+                                                            const unsigned *__restrict__ cell_start,
+                                                            const char *__restrict__ qraw, int stride, int n,
+                                                            int *__restrict__ idx, float *__restrict__ sqd)
+{
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const PairDesc &P = pairs[0];
+    const float *q = reinterpret_cast<const float *>(qraw + (size_t)i * stride);
+    float px = q[0], py = q[1], pz = q[2];
+    Best<K> B;
+    B.init();
+    if (finite3(px, py, pz)) knn_query<K>(P, sorted, cell_start, px, py, pz, B);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        bool ok = B.i[k] != 0x7fffffff;
+        idx[(size_t)i * K + k] = ok ? B.i[k] : -1;
+        sqd[(size_t)i * K + k] = ok ? B.d[k] : INFINITY;
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+// The fused ICP correspondence kernel.  One lane per source point (QPT points
+// per lane, strided by the block so loads stay coalesced).
+template <int QPT, bool WEIGHTED>
+__global__ __launch_bounds__(BLOCK) void icp_step_kernel(
+    const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
+    const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
+    const unsigned *__restrict__ cell_start, const float *__restrict__ pose32, int *__restrict__ nn_idx,
+    float *__restrict__ nn_sqd, double *__restrict__ partials, int nblk)
+{
+    constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
+    __shared__ double wsum[BLOCK / 64][NACC];
+    const int lb = xcd_remap(blockIdx.x, nblk);
+    const int b = __builtin_amdgcn_readfirstlane(blk_pair[lb]);
+    const int first = __builtin_amdgcn_readfirstlane(blk_first[lb]);
+    const PairDesc &P = pairs[b];
+    const float *T = pose32 + (size_t)b * 12;
+    const float r00 = T[0], r01 = T[1], r02 = T[2], tx = T[3];
+    const float r10 = T[4], r11 = T[5], r12 = T[6], ty = T[7];
+    const float r20 = T[8], r21 = T[9], r22 = T[10], tz = T[11];
+
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+
+#pragma unroll 1
+    for (int q = 0; q < QPT; ++q) {
+        int i = first + q * BLOCK + (int)threadIdx.x;
+        if (i >= P.n) continue;
+        float4 s = src4[P.src_off + i];
+        bool ok = finite3(s.x, s.y, s.z);
+        float px = __fmaf_rn(r00, s.x, __fmaf_rn(r01, s.y, __fmaf_rn(r02, s.z, tx)));
+        float py = __fmaf_rn(r10, s.x, __fmaf_rn(r11, s.y, __fmaf_rn(r12, s.z, ty)));
+        float pz = __fmaf_rn(r20, s.x, __fmaf_rn(r21, s.y, __fmaf_rn(r22, s.z, tz)));
+        Best<1> B;
+        B.init();
+        if (ok) knn_query<1>(P, sorted, cell_start, px, py, pz, B);
+        ok = ok && B.i[0] != 0x7fffffff;
+        nn_idx[P.src_off + i] = ok ? B.i[0] : -1;
+        nn_sqd[P.src_off + i] = ok ? B.d[0] : INFINITY;
+        if (!ok) continue;
+        float4 c = sorted[B.pos];
+        double dpx = px, dpy = py, dpz = pz, qx = c.x, qy = c.y, qz = c.z;
+        if (WEIGHTED) {
+            double w = wsrc[P.src_off + i], w2 = w * w;
+            acc[0] += w;
+            acc[1] += w * dpx; acc[2] += w * dpy; acc[3] += w * dpz;
+            acc[4] += w * qx;  acc[5] += w * qy;  acc[6] += w * qz;
+            double ax = w2 * dpx, ay = w2 * dpy, az = w2 * dpz;
+            acc[7] += ax * qx;  acc[8] += ax * qy;  acc[9] += ax * qz;
+            acc[10] += ay * qx; acc[11] += ay * qy; acc[12] += ay * qz;
+            acc[13] += az * qx; acc[14] += az * qy; acc[15] += az * qz;
+            acc[16] += sqrt((double)B.d[0]);
+            acc[17] += w2;
+            acc[18] += ax; acc[19] += ay; acc[20] += az;
+            acc[21] += w2 * qx; acc[22] += w2 * qy; acc[23] += w2 * qz;
+            acc[24] += 1.0;
+        } else {
+            acc[0] += 1.0;
+            acc[1] += dpx; acc[2] += dpy; acc[3] += dpz;
+            acc[4] += qx;  acc[5] += qy;  acc[6] += qz;
+            acc[7] += dpx * qx;  acc[8] += dpx * qy;  acc[9] += dpx * qz;
+            acc[10] += dpy * qx; acc[11] += dpy * qy; acc[12] += dpy * qz;
+            acc[13] += dpz * qx; acc[14] += dpz * qy; acc[15] += dpz * qz;
+            acc[16] += sqrt((double)B.d[0]);
+        }
+    }
+    // wave shuffle reduction, then the 4 wave totals through LDS (fixed order)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        double v = wave_sum(acc[k]);
+        if (lane == 0) wsum[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) v += wsum[w][threadIdx.x];
+        partials[(size_t)lb * NACC + threadIdx.x] = v;
+    }
+}
+
+// One wave per pair: reduce the pair's block partials in fixed order, solve the
+// rigid transform, compose the pose.  (TC:416-541 on 3-D data.)
+template <bool WEIGHTED>
+__global__ __launch_bounds__(64) void icp_solve_kernel(const PairDesc *__restrict__ pairs,
+                                                        const double *__restrict__ partials,
+                                                        double *__restrict__ pose64, float *__restrict__ pose32,
+                                                        double *__restrict__ err_hist, int it, int iters_cap)
+{
+    constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
+    const int b = blockIdx.x;
+    const PairDesc &P = pairs[b];
+    const int lane = threadIdx.x;
+    double a[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) a[k] = 0.0;
+    for (int j = lane; j < P.pblk_cnt; j += 64) {
+        const double *pp = partials + (size_t)(P.pblk_off + j) * NACC;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) a[k] += pp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) a[k] = wave_sum(a[k]);
+    if (lane != 0) return;
+
+    const double sw = a[0];
+    double *T = pose64 + (size_t)b * 16;
+    const double cnt = WEIGHTED ? a[24] : a[0];
+    if (err_hist) err_hist[(size_t)b * iters_cap + it] = cnt > 0.0 ? a[16] / cnt : 0.0;
+    if (!(sw > 0.0)) return;  // no correspondences: pose unchanged
+    double cp[3] = {a[1] / sw, a[2] / sw, a[3] / sw};
+    double cq[3] = {a[4] / sw, a[5] / sw, a[6] / sw};
+    double H[9];
+    if (WEIGHTED) {
+        // H = sum w^2 (p - cp)(q - cq)^T expanded in raw moments
+        const double sw2 = a[17];
+        const double sp2[3] = {a[18], a[19], a[20]}, sq2[3] = {a[21], a[22], a[23]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                H[3 * r + c] = a[7 + 3 * r + c] - cp[r] * sq2[c] - sp2[r] * cq[c] + sw2 * cp[r] * cq[c];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) H[3 * r + c] = a[7 + 3 * r + c] - sw * cp[r] * cq[c];
+    }
+    double R[9];
+    kabsch_from_H(H, R);
+    double t[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) t[r] = cq[r] - (R[3 * r] * cp[0] + R[3 * r + 1] * cp[1] + R[3 * r + 2] * cp[2]);
+    // T <- [R|t] * T
+    double Tn[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double v = R[3 * r] * T[c] + R[3 * r + 1] * T[4 + c] + R[3 * r + 2] * T[8 + c];
+            if (c == 3) v += t[r];
+            Tn[4 * r + c] = v;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        T[k] = Tn[k];
+        pose32[(size_t)b * 12 + k] = (float)Tn[k];
+    }
+}
+
+__global__ void pose_to_f32_kernel(const double *__restrict__ pose64, float *__restrict__ pose32, int npairs)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs * 12) return;
+    int b = i / 12, k = i % 12;
+    pose32[i] = (float)pose64[(size_t)b * 16 + k];
+}
+
+__global__ void unsort_nn_kernel(const PairDesc *__restrict__ pairs, const float4 *__restrict__ src4,
+                                 const int *__restrict__ nn_idx, const float *__restrict__ nn_sqd,
+                                 int *__restrict__ idx_out, float *__restrict__ sqd_out)
+{
+    int b = blockIdx.y;
+    const PairDesc &P = pairs[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += gridDim.x * blockDim.x) {
+        int orig = __float_as_int(src4[P.src_off + i].w);
+        idx_out[P.src_off + orig] = nn_idx[P.src_off + i];
+        sqd_out[P.src_off + orig] = nn_sqd[P.src_off + i];
+    }
+}
+
+__global__ void gather_weights_kernel(const PairDesc *__restrict__ pairs, const float4 *__restrict__ src4,
+                                      const double *__restrict__ w_in, double *__restrict__ w_sorted)
+{
+    int b = blockIdx.y;
+    const PairDesc &P = pairs[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += gridDim.x * blockDim.x) {
+        int orig = __float_as_int(src4[P.src_off + i].w);
+        w_sorted[P.src_off + i] = w_in[P.src_off + orig];
+    }
+}
+
+// ------------------------------------------------------------- host side
+
+struct GridSet {
+    gpscal_ctx *ctx = nullptr;
+    int npairs = 0;
+    std::vector<long long> off;  // npairs + 1 point offsets
+    std::vector<PairDesc> hpairs;
+    DevBuf<PairDesc> pairs;
+    DevBuf<float4> pts4;    // caller order
+    DevBuf<float4> sorted;  // all (pair, level) blocks
+    DevBuf<unsigned> cell_start;
+    long long total_cells = 0, total_sorted = 0;
+};
+
+// Chooses the level ladder for one cloud from its bounding box.
+static void plan_levels(const float mn[3], const float mx[3], int m, float cell, int max_levels, PairDesc &P)
+{
+    float ext[3], emax = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = mx[a] - mn[a];
+        if (!(ext[a] >= 0.f)) ext[a] = 0.f;
+        emax = std::max(emax, ext[a]);
+    }
+    float amax = 0.f;
+    for (int a = 0; a < 3; ++a) amax = std::max(amax, std::max(std::fabs(mn[a]), std::fabs(mx[a])));
+    float h0 = cell;
+    if (!(h0 > 0.f)) {
+        // lidar clouds are surfaces: aim at ~3 points per occupied cell of the
+        // footprint (the two largest extents)
+        float e0 = ext[0], e1 = ext[1], e2 = ext[2];
+        float area = std::max(e0 * e1, std::max(e0 * e2, e1 * e2));
+        h0 = std::sqrt(3.0f * area / (float)std::max(m, 1));
+    }
+    if (!(h0 > 0.f) || !std::isfinite(h0)) h0 = 1.0f;
+    h0 = std::max(h0, emax / 1024.0f);
+    // keep level 0 under 2^25 cells
+    for (;;) {
+        double nc = 1;
+        for (int a = 0; a < 3; ++a) nc *= std::floor(ext[a] / h0) + 1.0;
+        if (nc <= (double)(1 << 25)) break;
+        h0 *= 1.26f;
+    }
+    float htop = std::max(emax * 0.5f * 1.0001f, h0);  // <= 2 cells per axis: always conclusive
+    int L = 1;
+    float ratio = 4.0f;
+    if (htop > h0) {
+        L = 1 + (int)std::ceil(std::log(htop / h0) / std::log(4.0));
+        if (L > max_levels) L = max_levels;
+        if (L < 2) L = 2;
+        ratio = std::pow(htop / h0, 1.0f / (float)(L - 1));
+    }
+    P.nlevels = L;
+    float h = h0;
+    for (int l = 0; l < L; ++l) {
+        GridDesc &G = P.lv[l];
+        if (l == L - 1 && L > 1) h = htop;
+        G.ox = mn[0]; G.oy = mn[1]; G.oz = mn[2];
+        G.h = h;
+        G.inv_h = 1.0f / h;
+        G.nx = (int)std::floor(ext[0] / h) + 1;
+        G.ny = (int)std::floor(ext[1] / h) + 1;
+        G.nz = (int)std::floor(ext[2] / h) + 1;
+        // slack for the float rounding of cell assignment vs. face positions
+        G.margin = 1e-4f * h + 16.0f * 1.1920929e-7f * (amax + emax);
+        G.pad = 0;
+        h *= ratio;
+    }
+}
+
+static int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long long *off, int npairs,
+                       float cell, int max_levels, GridSet &gs)
+{
+    gs.ctx = ctx;
+    gs.npairs = npairs;
+    gs.off.assign(off, off + npairs + 1);
+    const long long total = off[npairs] - off[0];
+    if (total < 0) return fail(ctx, GPSCAL_EINVAL, "negative point count");
+    if (stride < 12) return fail(ctx, GPSCAL_EINVAL, "stride_bytes must be >= 12");
+    InArg<char> raw;
+    GPSCAL_HIP(ctx, raw.bind(ctx, static_cast<const char *>(xyz) + (size_t)off[0] * stride, (size_t)total * stride));
+    GPSCAL_HIP(ctx, gs.pts4.alloc((size_t)total));
+    DevBuf<long long> d_off;
+    GPSCAL_HIP(ctx, d_off.alloc(npairs + 1));
+    std::vector<long long> rel(npairs + 1);
+    for (int b = 0; b <= npairs; ++b) rel[b] = off[b] - off[0];
+    GPSCAL_HIP(ctx, hipMemcpyAsync(d_off.p, rel.data(), sizeof(long long) * (npairs + 1), hipMemcpyHostToDevice,
+                                   ctx->stream));
+    int mmax = 0;
+    for (int b = 0; b < npairs; ++b) {
+        long long m = rel[b + 1] - rel[b];
+        if (m < 0 || m > 0x7fffffff) return fail(ctx, GPSCAL_EINVAL, "bad offsets");
+        mmax = std::max(mmax, (int)m);
+    }
+    if (total > 0)
+        hipLaunchKernelGGL(pack_points_kernel, dim3(div_up(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, raw.dev,
+                           stride, d_off.p, npairs, total, gs.pts4.p);
+    // bounding boxes
+    DevBuf<int> d_bbox;
+    GPSCAL_HIP(ctx, d_bbox.alloc((size_t)npairs * 6));
+    std::vector<int> hb((size_t)npairs * 6);
+    for (int b = 0; b < npairs; ++b)
+        for (int a = 0; a < 3; ++a) {
+            hb[b * 6 + a] = 0x7fffffff;
+            hb[b * 6 + 3 + a] = (int)0x80000000;
+        }
+    GPSCAL_HIP(ctx, hipMemcpyAsync(d_bbox.p, hb.data(), sizeof(int) * hb.size(), hipMemcpyHostToDevice, ctx->stream));
+    int gx = std::max(1, std::min(div_up(mmax, BLOCK * 4), 256));
+    if (npairs > 0 && mmax > 0)
+        hipLaunchKernelGGL(bbox_kernel, dim3(gx, npairs), dim3(BLOCK), 0, ctx->stream, gs.pts4.p, d_off.p, d_bbox.p);
+    GPSCAL_HIP(ctx, hipMemcpyAsync(hb.data(), d_bbox.p, sizeof(int) * hb.size(), hipMemcpyDeviceToHost, ctx->stream));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    gs.hpairs.assign(npairs, PairDesc{});
+    long long cells = 0, sorted_total = 0;
+    for (int b = 0; b < npairs; ++b) {
+        PairDesc &P = gs.hpairs[b];
+        P.tgt_off = rel[b];
+        P.m = (int)(rel[b + 1] - rel[b]);
+        float mn[3], mx[3];
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = ord2f(hb[b * 6 + a]);
+            mx[a] = ord2f(hb[b * 6 + 3 + a]);
+            if (!(mn[a] <= mx[a])) mn[a] = mx[a] = 0.f;  // empty / all-NaN cloud
+        }
+        plan_levels(mn, mx, P.m, cell, max_levels, P);
+        for (int l = 0; l < P.nlevels; ++l) {
+            P.lv[l].cell_base = cells;
+            cells += (long long)P.lv[l].nx * P.lv[l].ny * P.lv[l].nz;
+            sorted_total += P.m;
+        }
+    }
+    if (sorted_total >= (1ll << 32) - 1) return fail(ctx, GPSCAL_ERANGE, "batch too large for 32-bit cell offsets");
+    gs.total_cells = cells;
+    gs.total_sorted = sorted_total;
+    GPSCAL_HIP(ctx, gs.pairs.alloc(npairs));
+    GPSCAL_HIP(ctx, hipMemcpyAsync(gs.pairs.p, gs.hpairs.data(), sizeof(PairDesc) * npairs, hipMemcpyHostToDevice,
+                                   ctx->stream));
+    DevBuf<unsigned> counts;
+    GPSCAL_HIP(ctx, counts.alloc((size_t)cells + 1));
+    GPSCAL_HIP(ctx, gs.cell_start.alloc((size_t)cells + 1));
+    GPSCAL_HIP(ctx, gs.sorted.alloc((size_t)sorted_total));
+    GPSCAL_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
+    if (npairs > 0 && mmax > 0) {
+        int gxf = std::max(1, std::min(div_up(mmax, BLOCK), 1024));
+        hipLaunchKernelGGL(grid_fill_kernel<0>, dim3(gxf, npairs), dim3(BLOCK), 0, ctx->stream, gs.pairs.p,
+                           gs.pts4.p, counts.p, (const unsigned *)nullptr, (float4 *)nullptr);
+        int rc = exclusive_scan(ctx, counts.p, gs.cell_start.p, cells + 1);
+        if (rc) return rc;
+        GPSCAL_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
+        hipLaunchKernelGGL(grid_fill_kernel<1>, dim3(gxf, npairs), dim3(BLOCK), 0, ctx->stream, gs.pairs.p,
+                           gs.pts4.p, counts.p, gs.cell_start.p, gs.sorted.p);
+    } else {
+        GPSCAL_HIP(ctx, hipMemsetAsync(gs.cell_start.p, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
+    }
+    GPSCAL_HIP(ctx, hipGetLastError());
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}
+
+}  // namespace gpscal
+
+using namespace gpscal;
+
+struct gpscal_knn_index {
+    gpscal_ctx *ctx;
+    GridSet gs;
+};
+
+struct gpscal_scan_batch {
+    gpscal_ctx *ctx = nullptr;
+    GridSet *tgt = nullptr;  // owned unless borrowed
+    bool borrowed = false;
+    int npairs = 0;
+    long long total_n = 0;
+    bool weighted = false;
+    int qpt = 1, nblk = 0;
+    DevBuf<PairDesc> pairs;  // target descs + source fields
+    std::vector<PairDesc> hpairs;
+    DevBuf<float4> src4;
+    DevBuf<double> wsorted;
+    DevBuf<int> blk_pair, blk_first;
+    DevBuf<int> nn_idx;
+    DevBuf<float> nn_sqd;
+    DevBuf<double> partials, pose64, err_hist;
+    DevBuf<float> pose32;
+    int err_cap = 0;
+    hipGraphExec_t graph = nullptr;
+    int graph_iters = 0;
+    double build_seconds = 0.0;
+    ~gpscal_scan_batch()
+    {
+        if (graph) (void)hipGraphExecDestroy(graph);
+        if (tgt && !borrowed) delete tgt;
+    }
+};
+
+// ------------------------------------------------------------ k-NN C ABI
+
+extern "C" int gpscal_knn_build(gpscal_ctx *ctx, const float *xyz, int m, int stride_bytes, float cell,
+                                gpscal_knn_index **index)
+{
+    if (!ctx || !index || m < 0 || (!xyz && m > 0)) return fail(ctx, GPSCAL_EINVAL, "gpscal_knn_build: bad argument");
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    auto *ix = new gpscal_knn_index;
+    ix->ctx = ctx;
+    long long off[2] = {0, m};
+    int rc = build_grids(ctx, xyz, stride_bytes, off, 1, cell, MAX_LEVELS, ix->gs);
+    if (rc) {
+        delete ix;
+        return rc;
+    }
+    *index = ix;
+    return GPSCAL_OK;
+}
+
+extern "C" int gpscal_knn_free(gpscal_knn_index *index)
+{
+    if (!index) return GPSCAL_EINVAL;
+    (void)hipSetDevice(index->ctx->device);
+    delete index;
+    return GPSCAL_OK;
+}
+
+template <int K>
+static void launch_search(gpscal_ctx *ctx, GridSet &gs, const char *q, int stride, int n, int *idx, float *sqd)
+{
+    hipLaunchKernelGGL(knn_search_kernel<K>, dim3(div_up(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, gs.pairs.p,
+                       gs.sorted.p, gs.cell_start.p, q, stride, n, idx, sqd);
+}
+
+extern "C" int gpscal_knn_search(gpscal_knn_index *index, const float *query, int n, int stride_bytes, int k,
+                                 int32_t *idx, float *sqd)
+{
+    if (!index) return GPSCAL_EINVAL;
+    gpscal_ctx *ctx = index->ctx;
+    if (n < 0 || k < 1 || k > 8 || stride_bytes < 12 || (n > 0 && (!query || !idx || !sqd)))
+        return fail(ctx, GPSCAL_EINVAL, "gpscal_knn_search: bad argument");
+    if (n == 0) return GPSCAL_OK;
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    InArg<char> q;
+    OutArg<int> oi;
+    OutArg<float> od;
+    GPSCAL_HIP(ctx, q.bind(ctx, reinterpret_cast<const char *>(query), (size_t)n * stride_bytes));
+    GPSCAL_HIP(ctx, oi.bind(ctx, idx, (size_t)n * k));
+    GPSCAL_HIP(ctx, od.bind(ctx, sqd, (size_t)n * k));
+    switch (k) {
+    case 1: launch_search<1>(ctx, index->gs, q.dev, stride_bytes, n, oi.dev, od.dev); break;
+    case 2: launch_search<2>(ctx, index->gs, q.dev, stride_bytes, n, oi.dev, od.dev); break;
+    case 3: launch_search<3>(ctx, index->gs, q.dev, stride_bytes, n, oi.dev, od.dev); break;
+    case 4: launch_search<4>(ctx, index->gs, q.dev, stride_bytes, n, oi.dev, od.dev); break;
+    case 5: launch_search<5>(ctx, index->gs, q.dev, stride_bytes, n, oi.dev, od.dev); break;
+    case 6: launch_search<6>(ctx, index->gs, q.dev, stride_bytes, n, oi.dev, od.dev); break;
+    case 7: launch_search<7>(ctx, index->gs, q.dev, stride_bytes, n, oi.dev, od.dev); break;
+    default: launch_search<8>(ctx, index->gs, q.dev, stride_bytes, n, oi.dev, od.dev); break;
+    }
+    GPSCAL_HIP(ctx, hipGetLastError());
+    bool sync = q.tmp.p != nullptr;  // staged input must outlive the kernel
+    GPSCAL_HIP(ctx, oi.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, od.commit(ctx, &sync));
+    if (sync) GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}
+
+// ------------------------------------------------------- scan batch C ABI
+
+static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int stride, const long long *src_off,
+                               const double *w)
+{
+    gpscal_ctx *ctx = B->ctx;
+    const int np = B->npairs;
+    // spatially group each source cloud by its own level-0 cells
+    GridSet sg;
+    int rc = build_grids(ctx, src_xyz, stride, src_off, np, 0.f, 1, sg);
+    if (rc) return rc;
+    B->total_n = sg.total_sorted;
+    // steal the grouped array: with one level `sorted` is exactly src4, except
+    // that non-finite points were dropped -- re-pack those at the tail.
+    B->hpairs = B->tgt->hpairs;
+    long long maxn = 0;
+    for (int b = 0; b < np; ++b) {
+        B->hpairs[b].src_off = sg.hpairs[b].tgt_off;
+        B->hpairs[b].n = sg.hpairs[b].m;
+        maxn = std::max<long long>(maxn, sg.hpairs[b].m);
+    }
+    // finite-point count per pair = cell_start at the end of the pair's cells
+    std::vector<unsigned> ends(np);
+    for (int b = 0; b < np; ++b) {
+        long long endcell = (b + 1 < np) ? sg.hpairs[b + 1].lv[0].cell_base : sg.total_cells;
+        GPSCAL_HIP(ctx, hipMemcpyAsync(&ends[b], sg.cell_start.p + endcell, sizeof(unsigned), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+    }
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned prev = 0;
+    for (int b = 0; b < np; ++b) {
+        unsigned finite = ends[b] - prev;
+        prev = ends[b];
+        if ((long long)finite != B->hpairs[b].n)
+            return fail(ctx, GPSCAL_EINVAL, "source cloud contains non-finite points (remove NaNs first, cf. scanRegistration.cpp:260-263)");
+    }
+    GPSCAL_HIP(ctx, B->src4.alloc((size_t)std::max<long long>(B->total_n, 1)));
+    GPSCAL_HIP(ctx, hipMemcpyAsync(B->src4.p, sg.sorted.p, sizeof(float4) * (size_t)B->total_n,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    // block table
+    const long long per_blk_target = (long long)ctx->prop.multiProcessorCount * 8 * BLOCK;
+    B->qpt = B->total_n >= 4 * per_blk_target ? 4 : 1;
+    std::vector<int> bp, bf;
+    for (int b = 0; b < np; ++b) {
+        PairDesc &P = B->hpairs[b];
+        P.pblk_off = (int)bp.size();
+        int per = BLOCK * B->qpt;
+        for (int f = 0; f < P.n; f += per) {
+            bp.push_back(b);
+            bf.push_back(f);
+        }
+        P.pblk_cnt = (int)bp.size() - P.pblk_off;
+    }
+    B->nblk = (int)bp.size();
+    GPSCAL_HIP(ctx, B->blk_pair.alloc(bp.size()));
+    GPSCAL_HIP(ctx, B->blk_first.alloc(bf.size()));
+    if (!bp.empty()) {
+        GPSCAL_HIP(ctx, hipMemcpyAsync(B->blk_pair.p, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice, ctx->stream));
+        GPSCAL_HIP(ctx, hipMemcpyAsync(B->blk_first.p, bf.data(), sizeof(int) * bf.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
+    GPSCAL_HIP(ctx, B->pairs.alloc(np));
+    GPSCAL_HIP(ctx, hipMemcpyAsync(B->pairs.p, B->hpairs.data(), sizeof(PairDesc) * np, hipMemcpyHostToDevice, ctx->stream));
+    B->weighted = w != nullptr;
+    if (w) {
+        InArg<double> win;
+        GPSCAL_HIP(ctx, win.bind(ctx, w, (size_t)B->total_n));
+        GPSCAL_HIP(ctx, B->wsorted.alloc((size_t)B->total_n));
+        int gx = std::max(1, std::min(div_up(maxn, BLOCK), 1024));
+        hipLaunchKernelGGL(gather_weights_kernel, dim3(gx, np), dim3(BLOCK), 0, ctx->stream, B->pairs.p, B->src4.p,
+                           win.dev, B->wsorted.p);
+        GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    GPSCAL_HIP(ctx, B->nn_idx.alloc((size_t)std::max<long long>(B->total_n, 1)));
+    GPSCAL_HIP(ctx, B->nn_sqd.alloc((size_t)std::max<long long>(B->total_n, 1)));
+    GPSCAL_HIP(ctx, B->partials.alloc((size_t)std::max(B->nblk, 1) * NACC_WEIGHTED));
+    GPSCAL_HIP(ctx, B->pose64.alloc((size_t)np * 16));
+    GPSCAL_HIP(ctx, B->pose32.alloc((size_t)np * 12));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return gpscal_scan_batch_set_pose(B, nullptr);
+}
+
+extern "C" int gpscal_scan_batch_create(gpscal_ctx *ctx, int npairs, const float *tgt_xyz, const int64_t *tgt_off,
+                                        const float *src_xyz, const int64_t *src_off, const double *w, float cell,
+                                        gpscal_scan_batch **batch)
+{
+    if (!ctx || !batch || npairs < 1 || !tgt_off || !src_off || !tgt_xyz || !src_xyz)
+        return fail(ctx, GPSCAL_EINVAL, "gpscal_scan_batch_create: bad argument");
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    auto t0 = std::chrono::steady_clock::now();
+    auto *B = new gpscal_scan_batch;
+    B->ctx = ctx;
+    B->npairs = npairs;
+    B->tgt = new GridSet;
+    std::vector<long long> to(tgt_off, tgt_off + npairs + 1), so(src_off, src_off + npairs + 1);
+    int rc = build_grids(ctx, tgt_xyz, 12, to.data(), npairs, cell, MAX_LEVELS, *B->tgt);
+    if (!rc) rc = batch_setup_sources(B, src_xyz, 12, so.data(), w);
+    if (rc) {
+        delete B;
+        return rc;
+    }
+    B->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *batch = B;
+    return GPSCAL_OK;
+}
+
+extern "C" int gpscal_scan_batch_set_pose(gpscal_scan_batch *B, const double *T0)
+{
+    if (!B) return GPSCAL_EINVAL;
+    gpscal_ctx *ctx = B->ctx;
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    const int np = B->npairs;
+    if (T0 && is_device_ptr(T0)) {
+        GPSCAL_HIP(ctx, hipMemcpyAsync(B->pose64.p, T0, sizeof(double) * 16 * np, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        std::vector<double> h((size_t)np * 16, 0.0);
+        for (int b = 0; b < np; ++b)
+            for (int k = 0; k < 16; ++k) h[(size_t)b * 16 + k] = T0 ? T0[(size_t)b * 16 + k] : (k % 5 == 0 ? 1.0 : 0.0);
+        GPSCAL_HIP(ctx, hipMemcpyAsync(B->pose64.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream));
+        GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    hipLaunchKernelGGL(pose_to_f32_kernel, dim3(div_up(np * 12, BLOCK)), dim3(BLOCK), 0, ctx->stream, B->pose64.p,
+                       B->pose32.p, np);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    return GPSCAL_OK;
+}
+
+static void launch_step(gpscal_scan_batch *B)
+{
+    gpscal_ctx *ctx = B->ctx;
+    GridSet &G = *B->tgt;
+    if (B->nblk == 0) return;
+#define STEP(QPT, W)                                                                                         \
+    hipLaunchKernelGGL((icp_step_kernel<QPT, W>), dim3(B->nblk), dim3(BLOCK), 0, ctx->stream, B->pairs.p,     \
+                       B->blk_pair.p, B->blk_first.p, B->src4.p, B->wsorted.p, G.sorted.p, G.cell_start.p,     \
+                       B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->partials.p, B->nblk)
+    if (B->weighted) {
+        if (B->qpt == 4) STEP(4, true); else STEP(1, true);
+    } else {
+        if (B->qpt == 4) STEP(4, false); else STEP(1, false);
+    }
+#undef STEP
+}
+
+static void launch_solve(gpscal_scan_batch *B, int it)
+{
+    gpscal_ctx *ctx = B->ctx;
+    if (B->weighted)
+        hipLaunchKernelGGL(icp_solve_kernel<true>, dim3(B->npairs), dim3(64), 0, ctx->stream, B->pairs.p,
+                           B->partials.p, B->pose64.p, B->pose32.p, B->err_hist.p, it, B->err_cap);
+    else
+        hipLaunchKernelGGL(icp_solve_kernel<false>, dim3(B->npairs), dim3(64), 0, ctx->stream, B->pairs.p,
+                           B->partials.p, B->pose64.p, B->pose32.p, B->err_hist.p, it, B->err_cap);
+}
+
+extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_out, double *mean_err,
+                                     float *step_ms)
+{
+    if (!B || iters < 0) return GPSCAL_EINVAL;
+    gpscal_ctx *ctx = B->ctx;
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    const int np = B->npairs;
+    if (iters > B->err_cap) {
+        if (B->graph) {
+            (void)hipGraphExecDestroy(B->graph);
+            B->graph = nullptr;
+        }
+        GPSCAL_HIP(ctx, B->err_hist.alloc((size_t)np * iters));
+        B->err_cap = iters;
+    }
+    if (step_ms) {
+        // profiling mode: every correspondence launch bracketed by HIP events
+        std::vector<hipEvent_t> ev((size_t)iters * 2);
+        for (auto &e : ev) GPSCAL_HIP(ctx, hipEventCreate(&e));
+        for (int it = 0; it < iters; ++it) {
+            GPSCAL_HIP(ctx, hipEventRecord(ev[2 * it], ctx->stream));
+            launch_step(B);
+            GPSCAL_HIP(ctx, hipEventRecord(ev[2 * it + 1], ctx->stream));
+            launch_solve(B, it);
+        }
+        GPSCAL_HIP(ctx, hipGetLastError());
+        GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int it = 0; it < iters; ++it) GPSCAL_HIP(ctx, hipEventElapsedTime(&step_ms[it], ev[2 * it], ev[2 * it + 1]));
+        for (auto &e : ev) (void)hipEventDestroy(e);
+    } else if (iters > 0) {
+        if (!B->graph || B->graph_iters != iters) {
+            if (B->graph) {
+                (void)hipGraphExecDestroy(B->graph);
+                B->graph = nullptr;
+            }
+            hipGraph_t g = nullptr;
+            GPSCAL_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            for (int it = 0; it < iters; ++it) {
+                launch_step(B);
+                launch_solve(B, it);
+            }
+            GPSCAL_HIP(ctx, hipStreamEndCapture(ctx->stream, &g));
+            GPSCAL_HIP(ctx, hipGraphInstantiate(&B->graph, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            B->graph_iters = iters;
+        }
+        GPSCAL_HIP(ctx, hipGraphLaunch(B->graph, ctx->stream));
+    }
+    bool sync = false;
+    if (T_out) {
+        if (is_device_ptr(T_out)) {
+            GPSCAL_HIP(ctx, hipMemcpyAsync(T_out, B->pose64.p, sizeof(double) * 16 * np, hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            GPSCAL_HIP(ctx, hipMemcpyAsync(T_out, B->pose64.p, sizeof(double) * 16 * np, hipMemcpyDeviceToHost, ctx->stream));
+            sync = true;
+        }
+    }
+    if (mean_err && iters > 0) {
+        // err_hist rows have stride err_cap; copy row by row when it differs
+        hipMemcpyKind kind = is_device_ptr(mean_err) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        GPSCAL_HIP(ctx, hipMemcpy2DAsync(mean_err, sizeof(double) * iters, B->err_hist.p, sizeof(double) * B->err_cap,
+                                         sizeof(double) * iters, np, kind, ctx->stream));
+        sync = sync || kind == hipMemcpyDeviceToHost;
+    }
+    if (sync) GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}
+
+extern "C" int gpscal_scan_batch_correspondences(gpscal_scan_batch *B, int32_t *idx, float *sqd)
+{
+    if (!B || !idx || !sqd) return GPSCAL_EINVAL;
+    gpscal_ctx *ctx = B->ctx;
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    OutArg<int> oi;
+    OutArg<float> od;
+    GPSCAL_HIP(ctx, oi.bind(ctx, idx, (size_t)B->total_n));
+    GPSCAL_HIP(ctx, od.bind(ctx, sqd, (size_t)B->total_n));
+    long long maxn = 0;
+    for (auto &P : B->hpairs) maxn = std::max<long long>(maxn, P.n);
+    int gx = std::max(1, std::min(div_up(maxn, BLOCK), 1024));
+    hipLaunchKernelGGL(unsort_nn_kernel, dim3(gx, B->npairs), dim3(BLOCK), 0, ctx->stream, B->pairs.p, B->src4.p,
+                       B->nn_idx.p, B->nn_sqd.p, oi.dev, od.dev);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    bool sync = false;
+    GPSCAL_HIP(ctx, oi.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, od.commit(ctx, &sync));
+    if (sync) GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}
+
+extern "C" double gpscal_scan_batch_build_seconds(gpscal_scan_batch *B) { return B ? B->build_seconds : 0.0; }
+
+extern "C" int gpscal_scan_batch_destroy(gpscal_scan_batch *B)
+{
+    if (!B) return GPSCAL_EINVAL;
+    (void)hipSetDevice(B->ctx->device);
+    (void)hipStreamSynchronize(B->ctx->stream);
+    delete B;
+    return GPSCAL_OK;
+}
+
+// --------------------------------------------- single-pair conveniences
+
+static int make_borrowed_batch(gpscal_ctx *ctx, gpscal_knn_index *index, const float *src, int n, int stride,
+                               const double *w, gpscal_scan_batch **out)
+{
+    if (!ctx || !index || !src || n < 1) return fail(ctx, GPSCAL_EINVAL, "gpscal_icp: bad argument");
+    auto *B = new gpscal_scan_batch;
+    B->ctx = ctx;
+    B->npairs = 1;
+    B->tgt = &index->gs;
+    B->borrowed = true;
+    long long so[2] = {0, n};
+    int rc = batch_setup_sources(B, src, stride, so, w);
+    if (rc) {
+        delete B;
+        return rc;
+    }
+    *out = B;
+    return GPSCAL_OK;
+}
+
+extern "C" int gpscal_icp_run(gpscal_ctx *ctx, gpscal_knn_index *index, const float *src_xyz, int n, int stride,
+                              const double *w, int iters, const double *T0, double *T_out, double *mean_err_hist)
+{
+    gpscal_scan_batch *B = nullptr;
+    int rc = make_borrowed_batch(ctx, index, src_xyz, n, stride, w, &B);
+    if (rc) return rc;
+    rc = gpscal_scan_batch_set_pose(B, T0);
+    if (!rc) rc = gpscal_scan_batch_icp(B, iters, T_out, mean_err_hist, nullptr);
+    (void)hipStreamSynchronize(ctx->stream);
+    delete B;
+    return rc;
+}
+
+extern "C" int gpscal_icp_iterate(gpscal_ctx *ctx, gpscal_knn_index *index, const float *src_xyz, int n, int stride,
+                                  const double *w, const double *T_in, double *T_out, double *mean_err)
+{
+    return gpscal_icp_run(ctx, index, src_xyz, n, stride, w, 1, T_in, T_out, mean_err);
+}

@@ -1,0 +1,176 @@
+"""Synthetic inputs of the shapes BASELINE.json / SURVEY.md section 8(d) name.
+
+No dataset ships with the reference besides data/original_gps_data.txt (the demo
+bags are an external download), so benchmarks and parity tests use generated
+data: lidar-like scan pairs (ground plane + walls + poles) and GPS/SLAM track
+segments with GPRMC logs.  numpy only; seeded, deterministic for a numpy version.
+"""
+import math
+
+import numpy as np
+
+
+def rot_zyx(yaw_deg=0.0, pitch_deg=0.0, roll_deg=0.0):
+    y, p, r = (math.radians(a) for a in (yaw_deg, pitch_deg, roll_deg))
+    Rz = np.array([[math.cos(y), -math.sin(y), 0], [math.sin(y), math.cos(y), 0], [0, 0, 1]])
+    Ry = np.array([[math.cos(p), 0, math.sin(p)], [0, 1, 0], [-math.sin(p), 0, math.cos(p)]])
+    Rx = np.array([[1, 0, 0], [0, math.cos(r), -math.sin(r)], [0, math.sin(r), math.cos(r)]])
+    return Rz @ Ry @ Rx
+
+
+def scan_scene(n, seed, half=50.0, sigma=0.01):
+    """n x 3 float32: 60 % ground (|x|,|y| < half), 30 % on 8 walls, 10 % on 32 poles."""
+    rng = np.random.default_rng(seed)
+    ng = int(round(0.6 * n))
+    nw = int(round(0.3 * n))
+    npole = n - ng - nw
+    g = np.empty((ng, 3))
+    g[:, 0:2] = rng.uniform(-half, half, size=(ng, 2))
+    g[:, 2] = 0.0
+    # 8 vertical walls, 20 m long x 5 m high, fixed layout from the seed-independent table
+    wall_rng = np.random.default_rng(12345)
+    wc = wall_rng.uniform(-0.8 * half, 0.8 * half, size=(8, 2))
+    wa = wall_rng.uniform(0, math.pi, size=8)
+    wi = rng.integers(0, 8, size=nw)
+    s = rng.uniform(-10.0, 10.0, size=nw)
+    w = np.empty((nw, 3))
+    w[:, 0] = wc[wi, 0] + s * np.cos(wa[wi])
+    w[:, 1] = wc[wi, 1] + s * np.sin(wa[wi])
+    w[:, 2] = rng.uniform(0.0, 5.0, size=nw)
+    pc = wall_rng.uniform(-0.9 * half, 0.9 * half, size=(32, 2))
+    pi = rng.integers(0, 32, size=npole)
+    ang = rng.uniform(0, 2 * math.pi, size=npole)
+    p = np.empty((npole, 3))
+    p[:, 0] = pc[pi, 0] + 0.1 * np.cos(ang)
+    p[:, 1] = pc[pi, 1] + 0.1 * np.sin(ang)
+    p[:, 2] = rng.uniform(0.0, 6.0, size=npole)
+    pts = np.concatenate([g, w, p], axis=0)
+    pts += rng.normal(0.0, sigma, size=pts.shape)
+    return pts.astype(np.float32)
+
+
+def scan_pair(n, pair_id=0, yaw_deg=None, pitch_deg=0.3, t=(0.50, 0.20, 0.05), sigma=0.01):
+    """(target, source, T_true) with source = T_true^-1-ish: source = R*target + t + noise, shuffled.
+
+    ICP recovers the transform that maps source back onto target, i.e. inverse(R, t).
+    SURVEY 8d cfg 2: yaw 2 deg; cfg 4: pair p uses seeds (2p+1, 2p+2), yaw 0.5 + 0.003 p.
+    """
+    if yaw_deg is None:
+        yaw_deg = 2.0 if pair_id == 0 else 0.5 + 0.003 * pair_id
+    tgt = scan_scene(n, 2 * pair_id + 1, sigma=sigma)
+    rng = np.random.default_rng(2 * pair_id + 2)
+    R = rot_zyx(yaw_deg, pitch_deg, 0.0)
+    src = tgt.astype(np.float64) @ R.T + np.asarray(t)
+    src += rng.normal(0.0, sigma, size=src.shape)
+    src = src[rng.permutation(len(src))].astype(np.float32)
+    T = np.eye(4)
+    T[:3, :3] = R.T
+    T[:3, 3] = -R.T @ np.asarray(t)
+    return tgt, src, T
+
+
+def scan_batch(npairs, n, first_pair=0):
+    """Packed arrays for ScanBatch: (tgt[npairs*n,3], off, src[npairs*n,3], off, T_true[npairs,4,4])."""
+    tg, sr, Ts = [], [], []
+    for p in range(first_pair, first_pair + npairs):
+        a, b, T = scan_pair(n, p)
+        tg.append(a)
+        sr.append(b)
+        Ts.append(T)
+    off = np.arange(npairs + 1, dtype=np.int64) * n
+    return np.concatenate(tg), off, np.concatenate(sr), off.copy(), np.stack(Ts)
+
+
+# ------------------------------------------------------------------ tracks
+def _nmea_ddmm(v, is_lat):
+    d = int(abs(v))
+    m = (abs(v) - d) * 60.0
+    return ("%02d%08.5f" if is_lat else "%03d%08.5f") % (d, m)
+
+
+def gprmc_line(t, lat, lon, valid=True):
+    """One line in the shipped log's format (data/original_gps_data.txt:1)."""
+    tm = int(t) % 86400
+    hms = "%02d%02d%02d.00" % (tm // 3600, (tm // 60) % 60, tm % 60)
+    body = "$GPRMC,%s,%s,%s,%s,%s,%s,0.447,,130517,,,A" % (
+        hms, "A" if valid else "V", _nmea_ddmm(lat, True), "N" if lat >= 0 else "S",
+        _nmea_ddmm(lon, False), "E" if lon >= 0 else "W")
+    cs = 0
+    for ch in body[1:]:
+        cs ^= ord(ch)
+    return "%.8f,%s*%02X" % (t, body, cs)
+
+
+def smooth_path(n, dt, seed, v_max=12.0):
+    """Smooth random-curvature path with stops: returns (xy[n,2] metres, speed[n])."""
+    rng = np.random.default_rng(seed)
+    kappa = np.cumsum(rng.normal(0, 0.002, size=n))
+    kappa -= np.linspace(0, kappa[-1], n)
+    kappa = np.clip(kappa, -0.03, 0.03)
+    v = np.clip(6.0 + np.cumsum(rng.normal(0, 0.15, size=n)), 0.0, v_max)
+    stop = rng.random(n) < 0.002
+    for i in np.flatnonzero(stop):
+        v[i:i + int(3.0 / dt)] = 0.0
+    heading = np.cumsum(kappa * v * dt) + rng.uniform(0, 2 * math.pi)
+    xy = np.cumsum(np.c_[v * np.cos(heading), v * np.sin(heading)] * dt, axis=0)
+    return xy, v
+
+
+def track_segments(nseg, poses, seed=7, rate_hz=10.0, gps_sigma=3.0, dropout=0.0, t0=1494650700.0,
+                   lat0=31.1779, lon0=121.3983):
+    """Synthetic GPS/SLAM inputs for the track path.
+
+    Returns dict(slam[N,4], enu_true[N,4] (only for sanity), seg_off[nseg+1], gprmc_text, gps(lat,lon,t,valid)).
+    Every segment's SLAM track starts at the origin with an unknown heading (LOAM is reset per
+    segment: laserOdometry.cpp:519-563), z = 10 (transformMaintenance.cpp:149).
+    """
+    rng = np.random.default_rng(seed)
+    dt = 1.0 / rate_hz
+    N = nseg * poses
+    xy, _ = smooth_path(N, dt, seed)
+    t = t0 + np.arange(N) * dt
+    # metres -> degrees around (lat0, lon0); northing = x, easting = y in the reference's convention
+    mlat = 111132.0
+    mlon = 111320.0 * math.cos(math.radians(lat0))
+    # GPS fixes at 1 Hz bracketing the SLAM span, true path + AR(1) noise
+    span = (N - 1) * dt
+    K = int(math.ceil(span + 0.7)) + 2
+    gt = t0 - 0.7 + np.arange(K)
+    gx = np.interp(gt, t, xy[:, 0])
+    gy = np.interp(gt, t, xy[:, 1])
+    noise = np.zeros((K, 2))
+    e = rng.normal(0, gps_sigma * math.sqrt(1 - 0.95 ** 2), size=(K, 2))
+    for k in range(1, K):
+        noise[k] = 0.95 * noise[k - 1] + e[k]
+    glat = lat0 + (gx + noise[:, 0]) / mlat
+    glon = lon0 + (gy + noise[:, 1]) / mlon
+    valid = np.ones(K, dtype=bool)
+    if dropout > 0 and K > 6:
+        k = 2
+        while k < K - 2:
+            if rng.random() < dropout / 6.0:
+                L = int(rng.integers(2, 11))
+                valid[k:min(k + L, K - 2)] = False
+                k += L
+            else:
+                k += 1
+    lines = []
+    for k in range(K):
+        lines.append(gprmc_line(gt[k], glat[k], glon[k], bool(valid[k])))
+        lines.append("")
+    text = "\n".join(lines) + "\n"
+    slam = np.empty((N, 4))
+    seg_off = np.arange(nseg + 1, dtype=np.int32) * poses
+    for s in range(nseg):
+        a, b = seg_off[s], seg_off[s + 1]
+        th = rng.uniform(0, 2 * math.pi)
+        c, sn = math.cos(th), math.sin(th)
+        loc = xy[a:b] - xy[a]
+        drift = np.cumsum(rng.normal(0, 0.002, size=(b - a, 2)), axis=0)
+        loc = loc + drift
+        slam[a:b, 0] = c * loc[:, 0] - sn * loc[:, 1]
+        slam[a:b, 1] = sn * loc[:, 0] + c * loc[:, 1]
+    slam[:, 2] = 10.0
+    slam[:, 3] = t
+    return {"slam": slam, "seg_off": seg_off, "gprmc": text, "xy_true": xy, "t": t,
+            "gps": (glat, glon, gt, valid)}

@@ -1,0 +1,221 @@
+/*
+ * gpscal.h -- C ABI of libgpscal_hip.so: the MI355X (gfx950) implementation of
+ * gpsCalibration's scan-matching + GPS/SLAM track-alignment hot path.
+ *
+ * This is the drop-in boundary.  The reference has no
+ * FFI seam of its own; the seams replaced are
+ *   (i)  the C++ class API of libgpsCalibration.so (CMakeLists.txt:141-147),
+ *        called from long_distance_track_process.cpp:58-83 and
+ *        short_distance_track_process.cpp:240-244, and
+ *   (ii) the pcl::KdTreeFLANN / Eigen calls inside the LOAM nodes.
+ * Each entry point cites the reference interface it replaces.  Citations use
+ * SURVEY.md's abbreviations, all under
+ * /root/reference/src/gpsCalibration/:
+ *   TC  = src/gps_calibration/track_calibration.cc   TC.h = include/gpsCalibration/track_calibration.h
+ *   WC  = src/gps_calibration/weight_calculation.cc  WC.h = include/gpsCalibration/weight_calculation.h
+ *   GP  = src/gps_calibration/gps_process.cc         GP.h = include/gpsCalibration/gps_process.h
+ *   CM.h= include/gpsCalibration/common.h
+ *   LD  = src/long_distance_track_process/long_distance_track_process.cpp
+ *   SD  = src/short_distance_track_process/short_distance_track_process.cpp
+ *   LO  = src/lidar_slam/loam/laserOdometry.cpp      LM = src/lidar_slam/loam/laserMapping.cpp
+ *   TM  = src/lidar_slam/loam/transformMaintenance.cpp
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative GPSCAL_E* code; the
+ *     library never calls exit() (the reference does: TC:49, GP:489,494,608);
+ *   - plain pointers and sizes only; the caller owns every buffer;
+ *   - a pointer may address HOST memory or DEVICE (HBM) memory: the library asks
+ *     the HIP runtime (hipPointerGetAttributes) and stages host buffers through
+ *     the context.  Device pointers are used in place, with no copy;
+ *   - all work is issued on the context's HIP stream; calls that hand results
+ *     to host memory synchronise that stream before returning, calls whose
+ *     outputs are all device pointers return as soon as the work is enqueued
+ *     (use gpscal_sync);
+ *   - a context is bound to one GPU and one host thread at a time (the
+ *     reference's nodes are single-threaded: LD:128-132, SD:223-231);
+ *   - there is NO CPU fallback: without a usable gfx950 device gpscal_create
+ *     fails with GPSCAL_ENODEV and nothing else can be called.
+ *
+ * Layouts (identical to the reference's structs / messages)
+ *   COORDXYZT  = double[4] {x,y,z,t}      CM.h:33-39, msg/IMLocalXYZT.msg
+ *   COORDXYZTW = double[5] {x,y,z,t,w}    CM.h:41-48, msg/IMLocalXYZTW.msg
+ *   clouds     = float xyz with a caller-given byte stride (12 = packed,
+ *                16 = pcl::PointXYZ, 32 = pcl::PointXYZI)
+ *   transforms = double[16], 4x4 row-major homogeneous (TC:529-542)
+ */
+#ifndef GPSCAL_H
+#define GPSCAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPSCAL_OK 0
+#define GPSCAL_EINVAL (-1)  /* bad argument                                   */
+#define GPSCAL_ENODEV (-2)  /* no gfx950 device / HIP runtime error at create */
+#define GPSCAL_EHIP (-3)    /* HIP runtime error (see gpscal_last_error)      */
+#define GPSCAL_ENOMEM (-4)  /* allocation failed                              */
+#define GPSCAL_ESIZE (-5)   /* track sizes differ (the reference exit(1)s, TC:46-50) */
+#define GPSCAL_ERANGE (-6)  /* output capacity too small                      */
+#define GPSCAL_ECOMM (-7)   /* RCCL error                                     */
+
+#define GPSCAL_METHOD_UTM 0      /* "UTM"      (run.sh ctm, GP:498)  */
+#define GPSCAL_METHOD_GAUSS 1    /* "Gaussion" (GP:502-505)          */
+
+typedef struct gpscal_ctx gpscal_ctx;
+typedef struct gpscal_knn_index gpscal_knn_index;
+typedef struct gpscal_scan_batch gpscal_scan_batch;
+
+/* ------------------------------------------------------------- lifecycle */
+int gpscal_create(gpscal_ctx **ctx, int device_id, unsigned flags);
+int gpscal_destroy(gpscal_ctx *ctx);
+int gpscal_sync(gpscal_ctx *ctx);
+/* The context's hipStream_t, for callers that bracket work with HIP events. */
+void *gpscal_stream(gpscal_ctx *ctx);
+const char *gpscal_strerror(int code);
+const char *gpscal_last_error(gpscal_ctx *ctx);
+/* "gfx950", CU count, library version; for logs. */
+int gpscal_device_info(gpscal_ctx *ctx, char *buf, size_t cap);
+
+/* --------------------------------------------------------------- weights */
+/* Replaces WeightCoeCal::ICPWeightCoeCal(slam, w) (WC:4-27, WC.h:14).
+ * slam_xyzt: n COORDXYZT; w: n doubles. */
+int gpscal_weights_speed(gpscal_ctx *ctx, const double *slam_xyzt, int n,
+                         double *w);
+/* Replaces WeightCoeCal::ICPWeightCoeCal(slam, w, enuOri, slamRotated)
+ * (WC:30-78, WC.h:16). */
+int gpscal_weights_irls(gpscal_ctx *ctx, const double *slam_xyzt,
+                        const double *enu_xyzt, const double *fit_xyzt, int n,
+                        double *w);
+
+/* ------------------------------------------------------- track alignment */
+/* Replaces trackCalibration(slam, enu, w) + doICP() + doCalibration(out)
+ * (TC:4-37; TC.h:12-23) for ONE segment.  Outputs (each may be NULL):
+ *   T               final 4x4 (TC:189), rotated_xyz n x 3 (TC:622),
+ *   calibrated_xyzt n COORDXYZT (TC:678-686). */
+int gpscal_track_fit(gpscal_ctx *ctx, const double *slam_xyzt,
+                     const double *enu_xyzt, const double *w, int n,
+                     double *T, double *rotated_xyz, double *calibrated_xyzt);
+/* Same for nseg independent segments in one launch.  seg_offsets has nseg+1
+ * entries (segment s owns rows [seg_offsets[s], seg_offsets[s+1]) of every
+ * array); T is nseg x 16.  This is what SD:234-245 does per queued track. */
+int gpscal_track_fit_batched(gpscal_ctx *ctx, const double *slam_xyzt,
+                             const double *enu_xyzt, const double *w,
+                             const int *seg_offsets, int nseg, double *T,
+                             double *rotated_xyz, double *calibrated_xyzt);
+/* Replaces the body of longDisTrackPro for one flag-0 track once its ENU GPS is
+ * known (LD:58-83): speed weights -> fit -> irls_iters x {IRLS weights ->
+ * fit(previous fit -> ENU)}.  w_out: final weights (what LD:83 merges);
+ * fit_out (may be NULL): last calibrated track, n COORDXYZT. */
+int gpscal_long_segment(gpscal_ctx *ctx, const double *slam_xyzt,
+                        const double *enu_xyzt, int n, int irls_iters,
+                        double *w_out, double *fit_out);
+int gpscal_long_segment_batched(gpscal_ctx *ctx, const double *slam_xyzt,
+                                const double *enu_xyzt, const int *seg_offsets,
+                                int nseg, int irls_iters, double *w_out,
+                                double *fit_out);
+
+/* -------------------------------------------------------------------- geo */
+/* Replaces GPSPro::UTMTransform / GaussionTransform (GP:851-908, 953-1007).
+ * lat/lon in degrees; band_type 3 or 6 (run.sh gdt); xy: n x {x = northing,
+ * y = easting + 500000 + band * 1e7}.  The band number comes from the first
+ * fix only, as in the reference (GP:869-877). */
+int gpscal_wgs_to_enu(gpscal_ctx *ctx, int method, int band_type,
+                      const double *lat, const double *lon, int n, double *xy);
+/* Replaces GPSPro::UTMReverseTransform / GaussionReverseTransform
+ * (GP:1010-1058, 911-950).  enu_xyztw: n COORDXYZTW; lonlat: n x {longitude,
+ * latitude} (GP:1053 order); alt: n (= z). */
+int gpscal_enu_to_wgs(gpscal_ctx *ctx, int method, int band_type,
+                      const double *enu_xyztw, int n, double *lonlat,
+                      double *alt);
+/* Replaces the arithmetic half of GPSPro::GPSToENU (GP:476-521) after the text
+ * has been parsed and dropouts filled on the host: projection of the ngps
+ * fixes (GP:498-505), linear interpolation at the SLAM stamps (GP:59-110) and
+ * assembly of {x, y, slam z, slam t} (GP:510-518).  *n_out receives the number
+ * of samples produced (stamps after the last fix are dropped, GP:99). */
+int gpscal_gps_to_enu(gpscal_ctx *ctx, int method, int band_type,
+                      const double *lat, const double *lon,
+                      const double *gps_t, int ngps, const double *slam_xyzt,
+                      int nslam, double *enu_xyzt, int *n_out);
+/* Replaces SaveTrailWithTimeTotxt's height compensation (TM:116-157) for a
+ * whole pose chain: in n x {px,py,pz,t} in LOAM axes, out n COORDXYZT. */
+int gpscal_height_compensate(gpscal_ctx *ctx, const double *loam_xyzt, int n,
+                             double *out_xyzt);
+
+/* ------------------------------------------------------------------ k-NN */
+/* Replaces pcl::KdTreeFLANN<PointType>::setInputCloud (LO:538-539,1119-1120;
+ * LM:750-751).  Builds the multi-level uniform-grid index over m points. */
+int gpscal_knn_build(gpscal_ctx *ctx, const float *xyz, int m,
+                     int stride_bytes, float cell_size_or_0,
+                     gpscal_knn_index **index);
+/* Replaces nearestKSearch(point, k, idx, sqd) (LO:603,758 k=1; LM:760,867 k=5),
+ * batched: all n queries of an iteration in one call.  Exact (eps = 0), results
+ * ascending by (squared distance, index); idx/sqd are n x k; missing
+ * neighbours (k > m) are idx -1 / sqd +inf.  1 <= k <= 8. */
+int gpscal_knn_search(gpscal_knn_index *index, const float *query_xyz, int n,
+                      int stride_bytes, int k, int32_t *idx, float *sqd);
+int gpscal_knn_free(gpscal_knn_index *index);
+
+/* ------------------------------------------------------------------- ICP */
+/* The generic scan-matching iteration (superset of
+ * TC:145-181): p_i = fl32(T) * src_i; exact 1-NN q_i of p_i in the target;
+ * centroids weighted by w, 3x3 cross-covariance by w^2 (TC:416-506); 3x3 SVD,
+ * R = V U^T with the reflection fix (TC:508-523), t = c_q - R c_p (TC:526);
+ * T <- [R|t] * T; mean NN distance reported.  A scan batch holds npairs
+ * independent (target, source) pairs resident in HBM: the unit that shards
+ * one-per-GPU.
+ * tgt_off / src_off: npairs+1 point offsets into the packed xyz arrays;
+ * w (may be NULL): one weight per source point. */
+int gpscal_scan_batch_create(gpscal_ctx *ctx, int npairs, const float *tgt_xyz,
+                             const int64_t *tgt_off, const float *src_xyz,
+                             const int64_t *src_off, const double *w,
+                             float cell_size_or_0, gpscal_scan_batch **batch);
+/* T0: npairs x 16 or NULL (identity). */
+int gpscal_scan_batch_set_pose(gpscal_scan_batch *batch, const double *T0);
+/* Runs `iters` iterations on every pair.  T_out npairs x 16; mean_err (may be
+ * NULL) npairs x iters (pair-major); step_ms (may be NULL) iters floats: when
+ * given, every launch of the correspondence kernel is bracketed by HIP events
+ * on the context stream and its duration returned (profiling mode, no graph).
+ * With step_ms == NULL the iteration chain is replayed from a captured
+ * hipGraph. */
+int gpscal_scan_batch_icp(gpscal_scan_batch *batch, int iters, double *T_out,
+                          double *mean_err, float *step_ms);
+/* Correspondences of the last iteration, in the caller's source order. */
+int gpscal_scan_batch_correspondences(gpscal_scan_batch *batch, int32_t *idx,
+                                      float *sqd);
+/* Seconds spent building the target indices and sorting the sources. */
+double gpscal_scan_batch_build_seconds(gpscal_scan_batch *batch);
+int gpscal_scan_batch_destroy(gpscal_scan_batch *batch);
+
+/* Single-pair conveniences over a prebuilt index (benchmark / LOAM shims). */
+int gpscal_icp_iterate(gpscal_ctx *ctx, gpscal_knn_index *index,
+                       const float *src_xyz, int n, int stride_bytes,
+                       const double *w, const double *T_in, double *T_out,
+                       double *mean_err);
+int gpscal_icp_run(gpscal_ctx *ctx, gpscal_knn_index *index,
+                   const float *src_xyz, int n, int stride_bytes,
+                   const double *w, int iters, const double *T0, double *T_out,
+                   double *mean_err_hist);
+
+/* ------------------------------------------------------------- multi-GPU */
+/* New (no reference counterpart): the one exchange of the sharded pipeline,
+ * an RCCL all-gather of per-segment pose chains / fit results over xGMI
+ * (SURVEY section 8e).  One process per GPU: rank 0 obtains an id with
+ * gpscal_comm_unique_id and hands it to the other ranks out of band. */
+#define GPSCAL_COMM_ID_BYTES 128
+int gpscal_comm_unique_id(void *id_bytes);
+int gpscal_comm_init(gpscal_ctx *ctx, const void *id_bytes, int rank,
+                     int world);
+/* local: count doubles on this rank; counts: world ints (doubles per rank);
+ * all: sum(counts) doubles, rank-major.  Pointers host or device. */
+int gpscal_allgather_chains(gpscal_ctx *ctx, const double *local,
+                            const int *counts, double *all);
+int gpscal_comm_destroy(gpscal_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSCAL_H */

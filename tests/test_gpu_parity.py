@@ -1,0 +1,359 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libgpscal_hip.so), against
+the CPU oracle on the same seeded inputs.  Bars:
+  * k-NN indices and squared distances: BIT-EXACT (integer / index work; both sides
+    compute fmaf(dz,dz,fmaf(dy,dy,dx*dx)) and order by (d2, index));
+  * one ICP iteration from the same pose: pose within 1e-9 (float64 reductions in a
+    different summation order);
+  * multi-iteration ICP: pose within 1e-5 (float32 rounding of the running pose may flip
+    individual correspondences);
+  * track path (float64): positions within 1e-6 m, weights within 1e-6 relative -- the
+    easting is ~4e8 m, where one float64 ulp is 6e-8 m; KML degrees within 1e-9
+    (north_star: 1e-6 deg);
+  * projections: within 1e-6 m / 1e-10 deg of the oracle (device libm vs glibc).
+"""
+import math
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from gpscalibration_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from gpscalibration_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+# -------------------------------------------------------------------- k-NN
+@pytest.mark.parametrize("k", [1, 5])
+@pytest.mark.parametrize("m,n", [(4096, 3000), (20000, 7777)])
+def test_knn_bit_exact_vs_oracle(ctx, k, m, n):
+    tgt = synth.scan_scene(m, 11)
+    rng = np.random.default_rng(5)
+    q = synth.scan_scene(n, 12) + rng.normal(0, 0.3, size=(n, 3)).astype(np.float32)
+    q[:100] = tgt[:100]  # exact hits
+    q[100:110] = np.array([500.0, -300.0, 80.0], dtype=np.float32)  # far outside the grid
+    ix = ctx.knn_index(tgt)
+    idx, sqd = ix.search(q, k)
+    kd = O.KdTree(tgt)
+    ridx, rsqd = kd.search(q, k)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(sqd, rsqd)
+    ix.close()
+
+
+def test_knn_ties_duplicates_and_small_clouds(ctx):
+    rng = np.random.default_rng(1)
+    tgt = (rng.normal(size=(1000, 3)) * 5).astype(np.float32)
+    tgt[500:600] = tgt[0:100]  # duplicates: the lower index must win
+    q = tgt[:200].copy()
+    ix = ctx.knn_index(tgt)
+    idx, sqd = ix.search(q, 2)
+    ridx, rsqd = O.knn_brute(tgt, q, 2)
+    assert np.array_equal(idx, ridx) and np.array_equal(sqd, rsqd)
+    assert np.all(idx[:100, 0] == np.arange(100)) and np.all(idx[:100, 1] == np.arange(500, 600))
+    ix.close()
+    # k larger than the cloud: missing neighbours are -1 / inf
+    small = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], dtype=np.float32)
+    ix = ctx.knn_index(small)
+    idx, sqd = ix.search(np.array([[0.4, 0, 0]], dtype=np.float32), 5)
+    assert list(idx[0]) == [0, 1, 2, -1, -1] and np.isinf(sqd[0, 3])
+    ix.close()
+    # single point, coplanar and collinear clouds
+    ix = ctx.knn_index(small[:1])
+    idx, sqd = ix.search(np.array([[3, 4, 0]], dtype=np.float32), 1)
+    assert idx[0, 0] == 0 and sqd[0, 0] == 25.0
+    ix.close()
+    line = np.c_[np.linspace(0, 100, 5000), np.zeros(5000), np.zeros(5000)].astype(np.float32)
+    ix = ctx.knn_index(line)
+    qq = (rng.uniform(-10, 110, size=(2000, 3)) * np.array([1, 0.05, 0.05])).astype(np.float32)
+    idx, sqd = ix.search(qq, 3)
+    ridx, rsqd = O.knn_brute(line, qq, 3)
+    assert np.array_equal(idx, ridx) and np.array_equal(sqd, rsqd)
+    ix.close()
+
+
+def test_knn_strided_pointxyzi_and_nan_points(ctx):
+    # pcl::PointXYZI is 32 bytes; NaN returns are skipped like
+    # removeNaNFromPointCloud does upstream (scanRegistration.cpp:260-263)
+    rng = np.random.default_rng(2)
+    m = 3000
+    raw = np.zeros((m, 8), dtype=np.float32)
+    raw[:, :3] = rng.normal(size=(m, 3)) * 8
+    raw[:, 4] = rng.uniform(0, 255, m)
+    raw[7, :3] = np.nan
+    ix = ctx.knn_index(raw, stride_bytes=32)
+    q = np.zeros((500, 8), dtype=np.float32)
+    q[:, :3] = rng.normal(size=(500, 3)) * 8
+    q[3, :3] = np.nan
+    idx, sqd = ix.search(q, 1, stride_bytes=32)
+    good = np.ones(m, dtype=bool)
+    good[7] = False
+    ridx, rsqd = O.knn_brute(raw[good, :3], q[:, :3], 1)
+    remap = np.flatnonzero(good)
+    ok = np.ones(500, dtype=bool)
+    ok[3] = False
+    assert np.array_equal(idx[ok, 0], remap[ridx[ok, 0]])
+    assert np.array_equal(sqd[ok, 0], rsqd[ok, 0])
+    assert idx[3, 0] == -1 and np.isinf(sqd[3, 0])
+    ix.close()
+
+
+def test_knn_device_pointers(ctx):
+    torch = pytest.importorskip("torch")
+    tgt = synth.scan_scene(8192, 3)
+    q = synth.scan_scene(4096, 4)
+    d_t = torch.from_numpy(tgt).cuda()
+    d_q = torch.from_numpy(q).cuda()
+    ix = ctx.knn_index(d_t)
+    d_i = torch.empty((4096, 1), dtype=torch.int32, device="cuda")
+    d_d = torch.empty((4096, 1), dtype=torch.float32, device="cuda")
+    ix.search(d_q, 1, out_idx=d_i, out_sqd=d_d)
+    ctx.sync()
+    ridx, rsqd = O.KdTree(tgt).search(q, 1)
+    assert np.array_equal(d_i.cpu().numpy(), ridx) and np.array_equal(d_d.cpu().numpy(), rsqd)
+    ix.close()
+
+
+# --------------------------------------------------------------------- ICP
+def test_icp_single_iteration_matches_oracle(ctx):
+    tgt, src, _ = synth.scan_pair(16384, 0)
+    off = np.array([0, len(tgt)], dtype=np.int64)
+    sb = ctx.scan_batch(tgt, off, src, off)
+    T, err, _ = sb.icp(1)
+    kd = O.KdTree(tgt)
+    T_ref, e_ref, idx_ref, sqd_ref = kd.icp_iterate(src, np.eye(4))
+    idx, sqd = sb.correspondences()
+    assert np.array_equal(idx, idx_ref) and np.array_equal(sqd, sqd_ref)  # bit-exact correspondences
+    assert np.abs(T[0] - T_ref).max() < 1e-9
+    assert abs(err[0, 0] - e_ref) < 1e-10
+    sb.close()
+
+
+def test_icp_weighted_iteration_matches_oracle(ctx):
+    tgt, src, _ = synth.scan_pair(8192, 3)
+    w = np.random.default_rng(0).uniform(0.1, 2.0, len(src))
+    off = np.array([0, len(tgt)], dtype=np.int64)
+    sb = ctx.scan_batch(tgt, off, src, off, w=w)
+    T0 = np.eye(4)
+    T0[:3, :3] = synth.rot_zyx(0.5, 0.1, -0.2)
+    T0[:3, 3] = [0.1, -0.2, 0.05]
+    sb.set_pose(T0[None])
+    T, err, _ = sb.icp(1)
+    T_ref, e_ref, _, _ = O.KdTree(tgt).icp_iterate(src, T0, w)
+    assert np.abs(T[0] - T_ref).max() < 1e-9
+    assert abs(err[0, 0] - e_ref) < 1e-10
+    sb.close()
+
+
+def test_icp_batched_run_matches_oracle_and_truth(ctx):
+    npairs, n = 6, 8192
+    tg, to, sr, so, T_true = synth.scan_batch(npairs, n)
+    sb = ctx.scan_batch(tg, to, sr, so)
+    T, err, _ = sb.icp(30)
+    for p in range(npairs):
+        kd = O.KdTree(tg[to[p]:to[p + 1]])
+        T_ref, hist = kd.icp_run(sr[so[p]:so[p + 1]], 30)
+        assert np.abs(T[p] - T_ref).max() < 1e-5, p
+        assert np.abs(err[p] - hist).max() < 1e-5
+        assert np.abs(T[p][:3, :3] - T_true[p][:3, :3]).max() < 2e-3
+        assert np.abs(T[p][:3, 3] - T_true[p][:3, 3]).max() < 0.05
+    # replaying the captured graph from the same start pose is deterministic, bit for bit
+    sb.set_pose(None)
+    T2, err2, _ = sb.icp(30)
+    assert np.array_equal(T, T2) and np.array_equal(err, err2)
+    # profiling mode (eager, event-bracketed) computes the same thing
+    sb.set_pose(None)
+    T3, _, ms = sb.icp(30, profile=True)
+    assert np.array_equal(T, T3) and ms.shape == (30,) and np.all(ms > 0)
+    sb.close()
+
+
+def test_icp_single_pair_api_over_prebuilt_index(ctx):
+    tgt, src, _ = synth.scan_pair(4096, 1)
+    ix = ctx.knn_index(tgt)
+    T, hist = ix.icp_run(src, 10)
+    T_ref, h_ref = O.KdTree(tgt).icp_run(src, 10)
+    assert np.abs(T - T_ref).max() < 1e-5 and np.abs(hist - h_ref).max() < 1e-5
+    ix.close()
+
+
+def test_icp_full_size_properties(ctx):
+    """BASELINE configs[1] size (65 536 points, 50 iterations): size-independent properties --
+    convergence to the generating transform, monotone-ish error, idempotence at the fixed point."""
+    tgt, src, T_true = synth.scan_pair(65536, 0)
+    off = np.array([0, len(tgt)], dtype=np.int64)
+    sb = ctx.scan_batch(tgt, off, src, off)
+    T, err, _ = sb.icp(50)
+    assert err[0, -1] < 0.05 < err[0, 0]
+    assert np.abs(T[0][:3, :3] - T_true[:3, :3]).max() < 1e-3
+    assert np.abs(T[0][:3, 3] - T_true[:3, 3]).max() < 0.02
+    assert abs(np.linalg.det(T[0][:3, :3]) - 1) < 1e-9
+    T_again, err2, _ = sb.icp(2)  # continue from the converged pose: nothing moves
+    assert np.abs(T_again[0] - T[0]).max() < 1e-4
+    idx, sqd = sb.correspondences()
+    assert idx.min() >= 0 and idx.max() < len(tgt)
+    # spot-check 2000 correspondences of the last iteration against brute force
+    sel = np.random.default_rng(0).choice(len(src), 2000, replace=False)
+    # pose used by the last iteration = pose before it; recompute from the first of the two
+    sb.set_pose(T[0][None])
+    sb.icp(1)
+    idx, sqd = sb.correspondences()
+    P = O.transform_f32(T[0], src[sel])
+    ridx, rsqd = O.knn_brute(tgt, P, 1)
+    assert np.array_equal(idx[sel], ridx[:, 0]) and np.array_equal(sqd[sel], rsqd[:, 0])
+    sb.close()
+
+
+# -------------------------------------------------------------------- track
+def _segments(nseg, poses, seed, dropout=0.0):
+    d = synth.track_segments(nseg, poses, seed=seed, dropout=dropout)
+    lat, lon, gt, valid = d["gps"]
+    lat = np.where(valid, lat, 90.0)
+    lon = np.where(valid, lon, 180.0)
+    la, lo, _ = O.gap_fill(lat, lon, gt)
+    return d, la, lo, gt
+
+
+def test_weights_match_oracle(ctx):
+    d, la, lo, gt = _segments(1, 500, 2)
+    slam = d["slam"]
+    enu = O.gps_to_enu(la, lo, gt, slam)
+    w = ctx.weights_speed(slam)
+    assert np.array_equal(w, O.weights_speed(slam))  # same operations, bit-exact
+    _, _, cal, _ = O.track_fit(slam, enu, w)
+    wi = ctx.weights_irls(slam, enu, cal)
+    np.testing.assert_allclose(wi, O.weights_irls(slam, enu, cal), rtol=1e-14)
+
+
+def test_gps_to_enu_and_back_match_oracle(ctx, gps_log_bytes):
+    st = 1494650700.0 + np.arange(1000)
+    slam = np.zeros((1000, 4))
+    slam[:, 2] = 10
+    slam[:, 3] = st
+    lat, lon, t = O.parse_gprmc(gps_log_bytes, st[0], st[-1])
+    enu = ctx.gps_to_enu(lat, lon, t, slam)
+    ref = O.gps_to_enu(lat, lon, t, slam)
+    assert enu.shape == ref.shape
+    assert np.abs(enu[:, :2] - ref[:, :2]).max() < 1e-6
+    assert np.array_equal(enu[:, 2:], ref[:, 2:])
+    # the reference-probe KAT through the GPU path
+    assert abs(enu[0, 0] - 3450164.856218) < 1e-5 and abs(enu[0, 1] - 400633250.787481) < 1e-5
+    e5 = np.c_[ref, np.ones(len(ref))]
+    ll, alt = ctx.enu_to_wgs(e5)
+    rll, ralt = O.local_to_wgs(e5)
+    assert np.abs(ll - rll).max() < 1e-10 and np.array_equal(alt, ralt)
+    assert abs(ll[0, 0] - 121.398330784171) < 1e-10 and abs(ll[0, 1] - 31.177944836485) < 1e-10
+    for method in ("UTM", "Gaussion"):
+        for band in (3, 6):
+            xy = ctx.wgs_to_enu(lat, lon, method, band)
+            rxy = O.wgs_to_local(lat, lon, 0 if method == "UTM" else 1, band)
+            assert np.abs(xy - rxy).max() < 1e-6, (method, band)
+
+
+def test_gps_to_enu_drops_stamps_after_last_fix(ctx):
+    d, la, lo, gt = _segments(1, 100, 4)
+    slam = d["slam"].copy()
+    slam[-5:, 3] = gt[-1] + 1.0 + np.arange(5)
+    enu = ctx.gps_to_enu(la, lo, gt, slam)
+    ref = O.gps_to_enu(la, lo, gt, slam)
+    assert len(enu) == len(ref) == 95
+
+
+@pytest.mark.parametrize("n", [2, 3, 64, 257, 400, 1250, 3000])
+def test_track_fit_matches_oracle(ctx, n):
+    d, la, lo, gt = _segments(1, n, 10 + n)
+    slam = d["slam"]
+    enu = O.gps_to_enu(la, lo, gt, slam)
+    w = O.weights_speed(slam)
+    T, rot, cal = ctx.track_fit(slam, enu, w)
+    T_ref, rot_ref, cal_ref, _ = O.track_fit(slam, enu, w)
+    assert np.abs(T - T_ref).max() < 1e-8
+    assert np.abs(rot - rot_ref).max() < 1e-7
+    assert np.abs(cal[:, :2] - cal_ref[:, :2]).max() < 1e-6
+    assert np.array_equal(cal[:, 2:], cal_ref[:, 2:])
+
+
+def test_track_fit_reflection_case_matches_oracle(ctx):
+    d, la, lo, gt = _segments(1, 300, 77)
+    slam = d["slam"].copy()
+    slam[:, 1] *= -1  # mirrored: det H2 < 0
+    enu = O.gps_to_enu(la, lo, gt, slam)
+    w = np.ones(len(slam))
+    T, rot, cal = ctx.track_fit(slam, enu, w)
+    T_ref, rot_ref, cal_ref, _ = O.track_fit(slam, enu, w)
+    assert T_ref[2, 2] == -1.0 and T[2, 2] == -1.0 and T[2, 3] == 2.0
+    assert np.abs(T - T_ref).max() < 1e-8
+    assert np.abs(cal[:, :2] - cal_ref[:, :2]).max() < 1e-6
+
+
+def test_track_fit_size_mismatch_is_an_error_not_exit(ctx):
+    from gpscalibration_amd import GpscalError
+    with pytest.raises(GpscalError):
+        ctx.track_fit(np.zeros((10, 4)), np.zeros((9, 4)), np.ones(10))
+
+
+def test_long_segment_batched_matches_oracle(ctx):
+    # ragged segments, 30 % dropout bursts (BASELINE configs[4] flavour)
+    nseg = 12
+    d, la, lo, gt = _segments(nseg, 400, 5, dropout=0.3)
+    slam = d["slam"]
+    enu = O.gps_to_enu(la, lo, gt, slam)
+    cuts = np.r_[0, np.cumsum([400, 380, 420, 10, 790, 400, 2, 398, 400, 400, 400, 400])].astype(np.int32)
+    assert cuts[-1] == len(slam)
+    w, fit = ctx.long_segment(slam, enu, 5, seg_offsets=cuts)
+    for s in range(nseg):
+        a, b = cuts[s], cuts[s + 1]
+        w_ref, fit_ref = O.long_segment(slam[a:b], enu[a:b], 5)
+        np.testing.assert_allclose(w[a:b], w_ref, rtol=1e-6, err_msg=str(s))
+        assert np.abs(fit[a:b, :2] - fit_ref[:, :2]).max() < 1e-6, s
+        assert np.array_equal(fit[a:b, 2:], fit_ref[:, 2:])
+
+
+def test_track_pipeline_kml_degrees(ctx):
+    """Long pass weights -> short pass fits -> merge -> WGS84: KML degrees vs the oracle chain."""
+    d, la, lo, gt = _segments(4, 300, 21)
+    slam, so = d["slam"], d["seg_off"]
+    enu = ctx.gps_to_enu(la, lo, gt, slam)
+    enu_ref = O.gps_to_enu(la, lo, gt, slam)
+    w, _ = ctx.long_segment(slam, enu, 5, seg_offsets=so)
+    T, rot, cal = ctx.track_fit(slam, enu, w, seg_offsets=so)
+    acc = acc_ref = None
+    for s in range(4):
+        a, b = so[s], so[s + 1]
+        w_ref, _ = O.long_segment(slam[a:b], enu_ref[a:b], 5)
+        _, _, cal_ref, _ = O.track_fit(slam[a:b], enu_ref[a:b], w_ref)
+        acc = O.merge_short(acc, cal[a:b], w[a:b])
+        acc_ref = O.merge_short(acc_ref, cal_ref, w_ref)
+    ll, _ = ctx.enu_to_wgs(acc)
+    ll_ref, _ = O.local_to_wgs(acc_ref)
+    assert np.abs(ll - ll_ref).max() < 1e-9  # degrees (north_star bar: 1e-6)
+
+
+def test_height_compensate_matches_oracle(ctx):
+    rng = np.random.default_rng(4)
+    p = np.c_[np.cumsum(rng.normal(0, 1, size=(200, 3)), axis=0), 10.0 + np.arange(200)]
+    out = ctx.height_compensate(p)
+    np.testing.assert_allclose(out, O.height_compensate(p), rtol=1e-13, atol=1e-12)
+
+
+def test_rccl_world_of_one(ctx):
+    """The RCCL path with a single rank: exercises dlopen, communicator setup and both the
+    equal-count and ragged code paths (multi-rank runs are the driver's 8-GPU bench)."""
+    import ctypes as C
+    L = ctx._L
+    uid = C.create_string_buffer(128)
+    assert L.gpscal_comm_unique_id(uid) == 0
+    assert L.gpscal_comm_init(ctx._h, uid, 0, 1) == 0
+    local = np.arange(32, dtype=np.float64)
+    counts = np.array([32], dtype=np.int32)
+    out = np.zeros(32)
+    assert L.gpscal_allgather_chains(ctx._h, local.ctypes.data, counts.ctypes.data, out.ctypes.data) == 0
+    assert np.array_equal(out, local)
+    assert L.gpscal_comm_destroy(ctx._h) == 0

@@ -1,0 +1,300 @@
+"""CPU tests (no GPU): the oracle against the fixtures and independent mathematics.
+
+The reference ships no tests or golden vectors.  What pins the
+oracle: (1) the known-answer values recorded in SURVEY.md section 8(c) from a probe of
+the reference's own gps_process.cc on data/original_gps_data.txt, (2) numpy's SVD,
+(3) an independent Krueger-series transverse Mercator, (4) brute force for the kd-tree,
+(5) algebraic identities of the track fit.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from gpscalibration_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------- reference KAT
+def test_survey_kat_gps_to_enu_and_back(gps_log_bytes):
+    """1000 stamps -> ENU (3450164.856218, 400633250.787481), back to
+    121.398330784, 31.177944836, KML line 121.398330784171,31.177944836485,10."""
+    st = 1494650700.0 + np.arange(1000)
+    slam = np.zeros((1000, 4))
+    slam[:, 2] = 10
+    slam[:, 3] = st
+    lat, lon, t = O.parse_gprmc(gps_log_bytes, st[0], st[-1])
+    assert len(lat) == 1002  # fixes within [(long)(t0-1), (long)(t1+1)]
+    enu = O.gps_to_enu(lat, lon, t, slam)
+    assert len(enu) == 1000
+    assert "%.6f" % enu[0, 0] == "3450164.856218"
+    assert "%.6f" % enu[0, 1] == "400633250.787481"
+    ll, alt = O.local_to_wgs(np.c_[enu, np.ones(len(enu))])
+    assert "%.9f %.9f" % (ll[0, 0], ll[0, 1]) == "121.398330784 31.177944836"
+    text = O.kml(ll, alt, 0)
+    assert "121.398330784171,31.177944836485,10\n" in text
+
+
+def test_parse_shipped_log_shape(gps_log_bytes):
+    lat, lon, t = O.parse_gprmc(gps_log_bytes, 1494650697.0, 1494653187.0)
+    assert len(lat) == 2490
+    assert np.all(np.diff(t) > 0)
+    assert abs(lat[0] - (31 + 10.67508 / 60)) < 1e-12
+    assert abs(lon[0] - (121 + 23.90009 / 60)) < 1e-12
+    assert not np.any((lat == 90) & (lon == 180))  # all status A
+
+
+def test_parse_status_v_and_hemispheres():
+    txt = ("100.5,$GPRMC,000001.00,A,3110.00000,S,12130.00000,W,0.1,,130517,,,A*00\n\n"
+           "101.5,$GPRMC,000002.00,V,,,,,,,130517,,,N*00\n\n"
+           "102.5,$GPRMC,000003.00,A,3111.00000,N,12131.00000,E,0.1,,130517,,,A*00\n")
+    lat, lon, t = O.parse_gprmc(txt, 100.0, 103.0)
+    assert list(t) == [100.5, 101.5, 102.5]
+    assert lat[0] == -(31 + 10.0 / 60) and lon[0] == -(121 + 30.0 / 60)
+    assert (lat[1], lon[1]) == (90.0, 180.0)  # sentinel, gps_process.cc:169,176-179
+    la, lo, rc = O.gap_fill(lat, lon, t)
+    assert rc == 0 and abs(la[1] - 0.5 * (lat[0] + lat[2])) < 1e-12
+
+
+def test_gap_fill_cases():
+    t = np.arange(8.0)
+    lat = np.array([1.0, 2.0, 90, 90, 5.0, 6.0, 90, 90])
+    lon = np.array([10.0, 20.0, 180, 180, 50.0, 60.0, 180, 180])
+    la, lo, rc = O.gap_fill(lat, lon, t)
+    assert rc == 0
+    np.testing.assert_allclose(la, [1, 2, 3, 4, 5, 6, 7, 8], atol=1e-12)  # middle + trailing
+    np.testing.assert_allclose(lo, [10, 20, 30, 40, 50, 60, 70, 80], atol=1e-11)
+    lat = np.array([90, 90, 3.0, 4.0, 5.0])
+    lon = np.array([180, 180, 30.0, 40.0, 50.0])
+    la, lo, rc = O.gap_fill(lat, lon, np.arange(5.0))
+    np.testing.assert_allclose(la, [1, 2, 3, 4, 5], atol=1e-12)  # leading gap: back-extrapolated
+    la, lo, rc = O.gap_fill(np.array([1.0, 90, 90]), np.array([1.0, 180, 180]), np.arange(3.0))
+    assert rc == 1  # one begin point only: cannot interpolate (gps_process.cc:444-447)
+
+
+# ---------------------------------------------------------------- projection
+def _krueger_tm(lat_deg, lon_deg, lon0_deg, k0, a=6378137.0, b=6356752.314):
+    """Independent transverse Mercator (Krueger n-series, 6th order)."""
+    f = (a - b) / a
+    n = f / (2 - f)
+    A = a / (1 + n) * (1 + n ** 2 / 4 + n ** 4 / 64 + n ** 6 / 256)
+    al = [n / 2 - 2 * n ** 2 / 3 + 5 * n ** 3 / 16 + 41 * n ** 4 / 180,
+          13 * n ** 2 / 48 - 3 * n ** 3 / 5 + 557 * n ** 4 / 1440,
+          61 * n ** 3 / 240 - 103 * n ** 4 / 140,
+          49561 * n ** 4 / 161280]
+    phi, lam = math.radians(lat_deg), math.radians(lon_deg - lon0_deg)
+    e = math.sqrt(f * (2 - f))
+    t = math.sinh(math.atanh(math.sin(phi)) - e * math.atanh(e * math.sin(phi)))
+    xi = math.atan2(t, math.cos(lam))
+    eta = math.atanh(math.sin(lam) / math.sqrt(1 + t * t))
+    N = xi + sum(al[j] * math.sin(2 * (j + 1) * xi) * math.cosh(2 * (j + 1) * eta) for j in range(4))
+    E = eta + sum(al[j] * math.cos(2 * (j + 1) * xi) * math.sinh(2 * (j + 1) * eta) for j in range(4))
+    return k0 * A * N, k0 * A * E
+
+
+def test_utm_forward_close_to_krueger():
+    # The reference's series (with its truncated PI and the misplaced A^6 term) must agree
+    # with an exact transverse Mercator to a few millimetres inside a 3-degree band.
+    lat = np.array([31.1779, 31.5, 30.2, -12.3, 45.0])
+    lon = np.array([121.3983, 120.2, 119.1, 120.9, 121.4])
+    xy = O.wgs_to_local(lat, lon, 0, 3)
+    for i in range(len(lat)):
+        n, e = _krueger_tm(lat[i], lon[i], 120.0, 0.9996)
+        assert abs(xy[i, 0] - n) < 0.02, (i, xy[i, 0] - n)
+        assert abs(xy[i, 1] - (e + 500000 + 40 * 1e7)) < 0.02
+
+
+def test_projection_round_trip_all_methods():
+    rng = np.random.default_rng(1)
+    lat = 31.0 + rng.uniform(-0.5, 0.5, 200)
+    lon = 121.4 + rng.uniform(-0.3, 0.3, 200)
+    for method in (0, 1):
+        for band in (3, 6):
+            xy = O.wgs_to_local(lat, lon, method, band)
+            enu = np.c_[xy, np.full(200, 10.0), np.zeros(200), np.ones(200)]
+            ll, alt = O.local_to_wgs(enu, method, band)
+            assert np.abs(ll[:, 0] - lon).max() < 2e-8, (method, band)
+            assert np.abs(ll[:, 1] - lat).max() < 2e-8
+            assert np.all(alt == 10.0)
+
+
+def test_interpolate_semantics():
+    xy = np.array([[0.0, 0.0], [10.0, 100.0], [20.0, 200.0]])
+    gt = np.array([10.0, 11.0, 12.0])
+    st = np.array([9.5, 10.0, 10.25, 11.0, 11.5, 12.0, 12.5])
+    out = O.interpolate(xy, gt, st)
+    assert len(out) == 6  # 12.5 dropped (gps_process.cc:99), 9.5 extrapolated
+    np.testing.assert_allclose(out[:, 0], [-5, 0, 2.5, 10, 15, 20], atol=1e-12)
+
+
+# --------------------------------------------------------------------- SVD
+def test_svd3_against_numpy():
+    rng = np.random.default_rng(0)
+    for i in range(500):
+        A = rng.normal(size=(3, 3)) * 10 ** rng.uniform(-3, 3)
+        if i % 5 == 0:
+            A[2, :] = 0
+            A[:, 2] = 0
+        U, S, V = O.svd3(A)
+        assert np.abs(U @ np.diag(S) @ V.T - A).max() <= 1e-13 * max(np.abs(A).max(), 1e-300)
+        np.testing.assert_allclose(S, np.linalg.svd(A, compute_uv=False), rtol=1e-12, atol=1e-13 * S[0])
+        assert np.abs(U.T @ U - np.eye(3)).max() < 1e-13 and np.abs(V.T @ V - np.eye(3)).max() < 1e-13
+        if i % 5 == 0:  # zero third row/col keeps e_z in both factors (track path relies on it)
+            assert abs(U[2, 2]) == 1.0 and abs(V[2, 2]) == 1.0
+
+
+def test_kabsch_reflection_fix_matches_numpy():
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        H = rng.normal(size=(3, 3))
+        U, S, Vt = np.linalg.svd(H)
+        R = Vt.T @ U.T
+        if np.linalg.det(R) < 0:
+            V = Vt.T.copy()
+            V[:, 2] *= -1
+            R = V @ U.T
+        assert np.abs(O.kabsch(H) - R).max() < 1e-12
+
+
+# ------------------------------------------------------------------- track
+def _segment(n=400, seed=0, theta=0.7, noise=2.0):
+    rng = np.random.default_rng(seed)
+    xy, _ = synth.smooth_path(n, 0.1, seed)
+    t = 1000.0 + 0.1 * np.arange(n)
+    c, s = math.cos(theta), math.sin(theta)
+    enu = np.c_[3450000 + xy[:, 0] + rng.normal(0, noise, n), 400633000 + xy[:, 1] + rng.normal(0, noise, n),
+                np.full(n, 10.0), t]
+    loc = xy - xy[0]
+    slam = np.c_[c * loc[:, 0] - s * loc[:, 1], s * loc[:, 0] + c * loc[:, 1], np.full(n, 10.0), t]
+    return slam, enu
+
+
+def test_speed_weights_rule():
+    slam, _ = _segment(50)
+    w = O.weights_speed(slam)
+    assert w[0] == 1.0
+    d = np.hypot(*(slam[2:, :2] - slam[1:-1, :2]).T)
+    np.testing.assert_allclose(w[1:-1], np.minimum(d / 2.2, 1.0), rtol=1e-15)
+    # last slot: the out-of-bounds read is defined as (0,0)
+    assert w[-1] == min(np.hypot(slam[-1, 0], slam[-1, 1]) / 2.2, 1.0)
+
+
+def test_track_fit_recovers_rigid_motion():
+    slam, enu = _segment(400, noise=0.0)
+    w = np.ones(len(slam))
+    T, rot, cal, iters = O.track_fit(slam, enu, w)
+    assert iters in (1, 2)
+    # noise-free: rotated SLAM + E0 reproduces the ENU track, and so does the calibrated track
+    assert np.abs(rot[:, 0] + enu[0, 0] - enu[:, 0]).max() < 1e-6
+    assert np.abs(cal[:, :2] - enu[:, :2]).max() < 1e-6
+    assert np.all(cal[:, 2:] == enu[:, 2:])
+    assert abs(np.linalg.det(T[:2, :2]) - 1) < 1e-12 and T[2, 2] == 1.0
+
+
+def test_track_fit_quadratic_equals_closed_form():
+    slam, enu = _segment(300, seed=3)
+    w = O.weights_speed(slam)
+    _, r1, c1, _ = O.track_fit(slam, enu, w, quadratic=True)
+    _, r2, c2, _ = O.track_fit(slam, enu, w, quadratic=False)
+    assert np.array_equal(r1, r2)
+    assert np.abs(c1 - c2).max() < 1e-7  # y ~ 4e8: one ulp is 6e-8
+
+
+def test_track_fit_reflection_case():
+    # mirrored SLAM track: det H2 < 0 -> the reference keeps V2 U2^T (a reflection) in xy and
+    # only flips R(2,2)
+    slam, enu = _segment(200, seed=5, noise=0.0)
+    slam[:, 1] *= -1
+    T, rot, cal, _ = O.track_fit(slam, enu, np.ones(len(slam)))
+    assert abs(np.linalg.det(T[:2, :2]) + 1) < 1e-12
+    assert T[2, 2] == -1.0 and T[2, 3] == 2.0
+    assert np.all(rot[:, 2] == 1.0)
+    assert np.abs(cal[:, :2] - enu[:, :2]).max() < 1e-6
+
+
+def test_long_segment_downweights_outliers():
+    slam, enu = _segment(500, seed=9, noise=0.5)
+    enu[100:110, :2] += 30.0  # multipath burst
+    w, fit = O.long_segment(slam, enu, 5)
+    assert np.median(w[100:110]) < 0.2 * np.median(w[200:400])
+    assert w.shape == (500,) and fit.shape == (500, 4)
+
+
+def test_match_and_merge_short():
+    n = 30
+    gps = np.c_[np.arange(n) * 1.0, np.zeros(n), np.full(n, 10.0), 100.0 + np.arange(n), np.linspace(1, 2, n)]
+    slam = np.c_[np.zeros(10), np.zeros(10), np.full(10, 10.0), 105.0 + np.arange(10)]
+    so, go, wo = O.match_gps(gps, slam)
+    assert len(so) == 10 and np.all(go[:, 3] == slam[:, 3]) and np.all(wo == gps[5:15, 4])
+    a = np.c_[np.arange(10.0), np.zeros(10), np.full(10, 10.0), 100.0 + np.arange(10)]
+    acc = O.merge_short(None, a, np.ones(10))
+    b = np.c_[np.arange(6, 16.0) + 1.0, np.zeros(10), np.full(10, 10.0), 106.0 + np.arange(10)]
+    acc = O.merge_short(acc, b, np.full(10, 3.0))
+    assert len(acc) == 16
+    assert np.all(acc[:6, 0] == np.arange(6.0))  # untouched head
+    assert np.all(acc[10:, 0] == np.arange(10, 16.0) + 1.0)  # appended tail
+    # overlap of 4: opNo=4, smWindow=2 -> new-segment share coe2 = 1/4, 2/4, 2/4, 3/4
+    # (short_distance_track_process.cpp:110-124: ramp in, plateau, ramp out of the OLD track)
+    np.testing.assert_allclose(acc[6:10, 0] - np.arange(6, 10.0), [0.25, 0.5, 0.5, 0.75])
+    np.testing.assert_allclose(acc[6:10, 4], 1 + 2 * np.array([0.25, 0.5, 0.5, 0.75]))
+
+
+def test_colour_segments_and_kml_quirks():
+    n = 40
+    enu = np.c_[np.arange(n) * 10.0, np.zeros(n), np.full(n, 10.0), np.arange(n) * 1.0, np.full(n, 0.5)]
+    end, rgb = O.colour_segments(enu)
+    assert list(end[:2]) == [6, 12]  # first index where the running distance exceeds 50 m
+    assert end[-1] == n - 1
+    ll = np.c_[121 + np.arange(n) * 1e-4, 31 + np.zeros(n)]
+    alt = np.full(n, 10.0)
+    txt = O.kml(ll, alt, 1, end, rgb)
+    assert txt.count("<Placemark>") == len(end)
+    coords = [l for l in txt.splitlines() if l.count(",") == 2 and l[0].isdigit()]
+    assert len(coords) == n - 1  # calibrated KML never writes the last point (gps_process.cc:832)
+    txt0 = O.kml(ll, alt, 0)
+    assert len([l for l in txt0.splitlines() if l.count(",") == 2 and l[0].isdigit()]) == n
+
+
+def test_height_compensation_keeps_step_length():
+    rng = np.random.default_rng(4)
+    p = np.cumsum(rng.normal(0, 1, size=(50, 3)), axis=0)
+    loam = np.c_[p, 10.0 + np.arange(50)]
+    out = O.height_compensate(loam)
+    d3 = np.linalg.norm(np.diff(p, axis=0), axis=1)
+    d2 = np.hypot(*np.diff(out[:, :2], axis=0).T)
+    np.testing.assert_allclose(d2, d3, rtol=1e-9)
+    assert np.all(out[:, 2] == 10.0)
+
+
+# ----------------------------------------------------------------- kNN/ICP
+@pytest.mark.parametrize("k", [1, 5])
+def test_kdtree_equals_brute_force(k):
+    rng = np.random.default_rng(0)
+    tgt = (rng.normal(size=(4000, 3)) * 10).astype(np.float32)
+    tgt[100:200] = tgt[0:100]  # exact duplicates: ties go to the lower index
+    q = (rng.normal(size=(1500, 3)) * 12).astype(np.float32)
+    q[:50] = tgt[:50]
+    i1, d1 = O.knn_brute(tgt, q, k)
+    i2, d2 = O.KdTree(tgt).search(q, k)
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    assert np.all(i1[:50, 0] == np.arange(50)) and np.all(d1[:50, 0] == 0)
+
+
+def test_knn_edge_cases():
+    tgt = np.array([[0, 0, 0], [1, 0, 0]], dtype=np.float32)
+    i, d = O.knn_brute(tgt, np.array([[0.4, 0, 0]], dtype=np.float32), 5)
+    assert list(i[0]) == [0, 1, -1, -1, -1] and np.isinf(d[0, 2])
+    i, d = O.KdTree(tgt).search(np.zeros((0, 3), dtype=np.float32), 1)
+    assert i.shape == (0, 1)
+
+
+def test_icp_recovers_transform():
+    tgt, src, T_true = synth.scan_pair(8192, 0)
+    kd = O.KdTree(tgt)
+    T, hist = kd.icp_run(src, 30)
+    assert hist[-1] < hist[0]
+    assert np.abs(T[:3, :3] - T_true[:3, :3]).max() < 2e-3
+    assert np.abs(T[:3, 3] - T_true[:3, 3]).max() < 0.05
