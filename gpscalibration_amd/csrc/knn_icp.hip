@@ -263,6 +263,13 @@ struct Best {
     __device__ __forceinline__ void consider(float d2, int idx, unsigned p)
     {
         if (d2 < d[K - 1] || (d2 == d[K - 1] && idx < i[K - 1])) {
+            if (K > 1) {
+                // a coarser level re-visits the points of the finer ones
+                bool dup = false;
+#pragma unroll
+                for (int s = 0; s < K - 1; ++s) dup |= i[s] == idx;
+                if (dup) return;
+            }
             d[K - 1] = d2;
             i[K - 1] = idx;
             if (K == 1) pos = p;
@@ -602,7 +609,7 @@ static void plan_levels(const float mn[3], const float mx[3], int m, float cell,
     float htop = std::max(emax * 0.5f * 1.0001f, h0);  // <= 2 cells per axis: always conclusive
     int L = 1;
     float ratio = 4.0f;
-    if (htop > h0) {
+    if (htop > h0 && max_levels > 1) {
         L = 1 + (int)std::ceil(std::log(htop / h0) / std::log(4.0));
         if (L > max_levels) L = max_levels;
         if (L < 2) L = 2;
