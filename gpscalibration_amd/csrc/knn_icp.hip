@@ -22,10 +22,12 @@
 // Roofline: HBM; algorithmic bytes per iteration = 20 n + 12 m.
 #include "common.hpp"
 #include "svd3.hpp"
+#include "wave_reduce.hpp"
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 
 namespace gpscal {
 
@@ -38,7 +40,7 @@ struct GridDesc {
     float ox, oy, oz, inv_h;
     float h, margin;
     int nx, ny, nz;
-    int pad;
+    int tile;  // 1: cells numbered in 8x8 xy tiles (source grouping only, never searched)
     long long cell_base;
 };
 
@@ -152,6 +154,12 @@ __device__ __forceinline__ long long cell_of(const GridDesc &G, float x, float y
     int cx = cell_coord(x, G.ox, G.inv_h, G.nx);
     int cy = cell_coord(y, G.oy, G.inv_h, G.ny);
     int cz = cell_coord(z, G.oz, G.inv_h, G.nz);
+    if (G.tile) {
+        // 8x8 tiles in xy keep 256 consecutive points a compact patch, so the
+        // fused kernel's LDS box stays small
+        const int ntx = (G.nx + 7) >> 3, nty = (G.ny + 7) >> 3;
+        return G.cell_base + ((((long long)cz * nty + (cy >> 3)) * ntx + (cx >> 3)) << 6) + ((cy & 7) << 3) + (cx & 7);
+    }
     return G.cell_base + ((long long)cz * G.ny + cy) * G.nx + cx;
 }
 
@@ -249,7 +257,6 @@ template <int K>
 struct Best {
     float d[K];
     int i[K];
-    unsigned pos;  // position of the best candidate in `sorted` (K == 1 use)
     __device__ __forceinline__ void init()
     {
 #pragma unroll
@@ -257,11 +264,11 @@ struct Best {
             d[k] = INFINITY;
             i[k] = 0x7fffffff;
         }
-        pos = 0;
     }
     __device__ __forceinline__ float worst() const { return d[K - 1]; }
-    __device__ __forceinline__ void consider(float d2, int idx, unsigned p)
+    __device__ __forceinline__ void consider(float d2, const float4 &c, unsigned)
     {
+        const int idx = __float_as_int(c.w);
         if (d2 < d[K - 1] || (d2 == d[K - 1] && idx < i[K - 1])) {
             if (K > 1) {
                 // a coarser level re-visits the points of the finer ones
@@ -272,7 +279,6 @@ struct Best {
             }
             d[K - 1] = d2;
             i[K - 1] = idx;
-            if (K == 1) pos = p;
 #pragma unroll
             for (int s = K - 1; s > 0; --s) {
                 bool sw = d[s] < d[s - 1] || (d[s] == d[s - 1] && i[s] < i[s - 1]);
@@ -285,58 +291,89 @@ struct Best {
     }
 };
 
-template <int K>
-__device__ __forceinline__ void scan_run(Best<K> &B, const float4 *__restrict__ sorted, unsigned s, unsigned e,
+// 1-NN record of the ICP kernel: keeps the neighbour's coordinates (no second
+// gather) and its position in `sorted` (next iteration's warm start).
+struct BestQ {
+    float d;
+    int i;
+    unsigned pos;
+    float x, y, z;
+    __device__ __forceinline__ void init()
+    {
+        d = INFINITY;
+        i = 0x7fffffff;
+        pos = 0xffffffffu;
+        x = y = z = 0.f;
+    }
+    __device__ __forceinline__ float worst() const { return d; }
+    __device__ __forceinline__ void consider(float d2, const float4 &c, unsigned p)
+    {
+        const int idx = __float_as_int(c.w);
+        if (d2 < d || (d2 == d && idx < i)) {
+            d = d2;
+            i = idx;
+            pos = p;
+            x = c.x;
+            y = c.y;
+            z = c.z;
+        }
+    }
+};
+
+// Four consecutive cell_start entries fetched as ONE 16-byte load (dword aligned).
+struct __attribute__((packed, aligned(4))) CellQuad {
+    unsigned a, b, c, d;
+};
+
+// Candidates [s, e) of `sorted` in HBM/L2, four 16-byte loads in flight per lane.
+template <class BT>
+__device__ __forceinline__ void scan_run(BT &B, const float4 *__restrict__ sorted, unsigned s, unsigned e,
                                          float px, float py, float pz)
 {
-    for (unsigned j = s; j < e; ++j) {
-        float4 c = sorted[j];
-        B.consider(sqdist(px, py, pz, c.x, c.y, c.z), __float_as_int(c.w), j);
+    for (unsigned j = s; j < e; j += 4) {
+        const unsigned last = e - 1;
+        float4 c0 = sorted[j];
+        float4 c1 = sorted[min(j + 1, last)];
+        float4 c2 = sorted[min(j + 2, last)];
+        float4 c3 = sorted[min(j + 3, last)];
+        B.consider(sqdist(px, py, pz, c0.x, c0.y, c0.z), c0, j);
+        if (j + 1 < e) B.consider(sqdist(px, py, pz, c1.x, c1.y, c1.z), c1, j + 1);
+        if (j + 2 < e) B.consider(sqdist(px, py, pz, c2.x, c2.y, c2.z), c2, j + 2);
+        if (j + 3 < e) B.consider(sqdist(px, py, pz, c3.x, c3.y, c3.z), c3, j + 3);
     }
 }
 
-// Exact k-NN of (px,py,pz) in pair P.  Levels are visited fine -> coarse; a
-// level's 3x3x3 block of cells settles the query when the k-th best distance is
-// within the distance to the nearest face of the block that still has cells
-// behind it.  The coarsest level has <= 2 cells per axis, so it always settles.
-template <int K>
-__device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__restrict__ sorted,
-                                          const unsigned *__restrict__ cell_start, float px, float py, float pz,
-                                          Best<K> &B)
+// Same over the LDS-staged tile: global position j lives at lpts[j - delta].
+template <class BT>
+__device__ __forceinline__ void scan_run_lds(BT &B, const float4 *lpts, unsigned s, unsigned e, unsigned delta,
+                                             float px, float py, float pz)
 {
-    B.init();
-    for (int l = 0; l < P.nlevels; ++l) {
-        const GridDesc &G = P.lv[l];
-        const float h = G.h, mg = G.margin;
-        int cx = cell_coord(px, G.ox, G.inv_h, G.nx);
-        int cy = cell_coord(py, G.oy, G.inv_h, G.ny);
-        int cz = cell_coord(pz, G.oz, G.inv_h, G.nz);
-        // distances from p to the faces of its own cell (may be < 0 when p was clamped)
-        float fy0 = py - (G.oy + cy * h), fy1 = (G.oy + (cy + 1) * h) - py;
-        float fz0 = pz - (G.oz + cz * h), fz1 = (G.oz + (cz + 1) * h) - pz;
-        float fx0 = px - (G.ox + cx * h), fx1 = (G.ox + (cx + 1) * h) - px;
-        int xlo = max(cx - 1, 0), xhi = min(cx + 1, G.nx - 1);
-#pragma unroll
-        for (int rz = 0; rz < 3; ++rz) {
-            int dz = rz == 0 ? 0 : (rz == 1 ? -1 : 1);
-            int zz = cz + dz;
-            if (zz < 0 || zz >= G.nz) continue;
-            float bz = dz == 0 ? 0.f : fmaxf((dz < 0 ? fz0 : fz1) - mg, 0.f);
-#pragma unroll
-            for (int ry = 0; ry < 3; ++ry) {
-                int dy = ry == 0 ? 0 : (ry == 1 ? -1 : 1);
-                int yy = cy + dy;
-                if (yy < 0 || yy >= G.ny) continue;
-                float by = dy == 0 ? 0.f : fmaxf((dy < 0 ? fy0 : fy1) - mg, 0.f);
-                float rb2 = by * by + bz * bz;
-                if (rb2 * 0.99999f > B.worst()) continue;  // row cannot hold a better point
-                long long row = G.cell_base + ((long long)zz * G.ny + yy) * G.nx;
-                unsigned s = cell_start[row + xlo];
-                unsigned e = cell_start[row + xhi + 1];
-                scan_run<K>(B, sorted, s, e, px, py, pz);
-            }
-        }
-        // guaranteed radius of this level
+    for (unsigned j = s; j < e; j += 2) {
+        float4 c0 = lpts[j - delta];
+        float4 c1 = lpts[min(j + 1, e - 1) - delta];
+        B.consider(sqdist(px, py, pz, c0.x, c0.y, c0.z), c0, j);
+        if (j + 1 < e) B.consider(sqdist(px, py, pz, c1.x, c1.y, c1.z), c1, j + 1);
+    }
+}
+
+// Per-query geometry at one grid level.
+struct CellGeo {
+    int cx, cy, cz;
+    float fx0, fx1, fy0, fy1, fz0, fz1;  // distances to the faces of the own cell
+    __device__ __forceinline__ void set(const GridDesc &G, float px, float py, float pz)
+    {
+        cx = cell_coord(px, G.ox, G.inv_h, G.nx);
+        cy = cell_coord(py, G.oy, G.inv_h, G.ny);
+        cz = cell_coord(pz, G.oz, G.inv_h, G.nz);
+        const float h = G.h;
+        fx0 = px - (G.ox + cx * h); fx1 = (G.ox + (cx + 1) * h) - px;
+        fy0 = py - (G.oy + cy * h); fy1 = (G.oy + (cy + 1) * h) - py;
+        fz0 = pz - (G.oz + cz * h); fz1 = (G.oz + (cz + 1) * h) - pz;
+    }
+    // squared radius inside which this level's 3x3x3 block is exhaustive
+    __device__ __forceinline__ float settled_r2(const GridDesc &G) const
+    {
+        const float h = G.h;
         float g = INFINITY;
         if (cx - 1 > 0) g = fminf(g, fx0 + h);
         if (cx + 1 < G.nx - 1) g = fminf(g, fx1 + h);
@@ -344,8 +381,60 @@ __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__res
         if (cy + 1 < G.ny - 1) g = fminf(g, fy1 + h);
         if (cz - 1 > 0) g = fminf(g, fz0 + h);
         if (cz + 1 < G.nz - 1) g = fminf(g, fz1 + h);
-        g = fmaxf(g - mg, 0.f);
-        if (B.worst() <= g * g * 0.99999f || g == INFINITY) break;
+        g = fmaxf(g - G.margin, 0.f);
+        return g == INFINITY ? INFINITY : g * g * 0.99999f;
+    }
+};
+
+// One level of the search out of global memory.
+template <class BT>
+__device__ __forceinline__ void knn_level_global(const GridDesc &G, const CellGeo &C, const float4 *__restrict__ sorted,
+                                                 const unsigned *__restrict__ cell_start, float px, float py,
+                                                 float pz, BT &B)
+{
+    const float mg = G.margin;
+    const float bxl = fmaxf(C.fx0 - mg, 0.f), bxr = fmaxf(C.fx1 - mg, 0.f);
+    const bool has_l = C.cx > 0, has_r = C.cx + 1 < G.nx;
+#pragma unroll 1
+    for (int r = 0; r < 9; ++r) {
+        const int kz = r / 3, ky = r - 3 * kz;
+        const int dz = kz == 0 ? 0 : (kz == 1 ? -1 : 1);
+        const int dy = ky == 0 ? 0 : (ky == 1 ? -1 : 1);
+        const int zz = C.cz + dz, yy = C.cy + dy;
+        if (zz < 0 || zz >= G.nz || yy < 0 || yy >= G.ny) continue;
+        const float bz = dz == 0 ? 0.f : fmaxf((dz < 0 ? C.fz0 : C.fz1) - mg, 0.f);
+        const float by = dy == 0 ? 0.f : fmaxf((dy < 0 ? C.fy0 : C.fy1) - mg, 0.f);
+        const float rb2 = by * by + bz * bz;
+        if (rb2 * 0.99999f > B.worst()) continue;  // row cannot hold a better point
+        const long long row = G.cell_base + ((long long)zz * G.ny + yy) * G.nx + C.cx;
+        // cell_start[row-1 .. row+2]: left | own | right cell boundaries
+        const CellQuad q = *reinterpret_cast<const CellQuad *>(cell_start + row - 1);
+        const unsigned c0 = has_l ? q.a : q.b, c1 = q.b, c2 = q.c, c3 = has_r ? q.d : q.c;
+        scan_run(B, sorted, c1, c2, px, py, pz);
+        if (c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst()) scan_run(B, sorted, c0, c1, px, py, pz);
+        if (c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst()) scan_run(B, sorted, c2, c3, px, py, pz);
+    }
+}
+
+// Exact k-NN of (px,py,pz) in pair P, levels first_level.. fine -> coarse.  A
+// level's 3x3x3 block of cells settles the query when the k-th best distance is
+// within the distance to the nearest face of the block that still has cells
+// behind it.  The coarsest level has <= 2 cells per axis, so it always settles.
+// Rows (fixed y,z; x-1..x+1 contiguous in memory) and then single cells are
+// skipped when their nearest face is already farther than the k-th best, so a
+// good starting candidate (the previous iteration's neighbour) removes most of
+// the memory traffic.
+template <class BT>
+__device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__restrict__ sorted,
+                                          const unsigned *__restrict__ cell_start, float px, float py, float pz,
+                                          BT &B, int first_level = 0)
+{
+    for (int l = first_level; l < P.nlevels; ++l) {
+        const GridDesc &G = P.lv[l];
+        CellGeo C;
+        C.set(G, px, py, pz);
+        knn_level_global(G, C, sorted, cell_start, px, py, pz, B);
+        if (B.worst() <= C.settled_r2(G)) break;
     }
 }
 
@@ -364,7 +453,7 @@ __global__ __launch_bounds__(BLOCK) void knn_search_kernel(const PairDesc *__res
     float px = q[0], py = q[1], pz = q[2];
     Best<K> B;
     B.init();
-    if (finite3(px, py, pz)) knn_query<K>(P, sorted, cell_start, px, py, pz, B);
+    if (finite3(px, py, pz)) knn_query(P, sorted, cell_start, px, py, pz, B);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         bool ok = B.i[k] != 0x7fffffff;
@@ -373,32 +462,48 @@ __global__ __launch_bounds__(BLOCK) void knn_search_kernel(const PairDesc *__res
     }
 }
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
-    return v;
-}
+// ---- LDS tile limits of the fused kernel (bytes: 16*MAXP + 4*MAXCS + small)
+constexpr int T_MAXP = 1536;   // staged target points
+constexpr int T_MAXCS = 1536;  // staged cell_start entries
+constexpr int T_MAXR = 96;     // rows (y,z) of the staged box
 
-// The fused ICP correspondence kernel.  One lane per source point (QPT points
-// per lane, strided by the block so loads stay coalesced).
+// The fused ICP correspondence kernel: transform -> exact 1-NN -> weighted
+// centroid / covariance partials.  One lane per source point, 256 consecutive
+// points of the spatially grouped source per workgroup (QPT batches of 256).
+//
+// Level 0 of the search runs out of LDS: the workgroup's queries are spatially
+// coherent, so the union of their 3x3x3 cell blocks is a small box of the
+// target grid.  Its rows are contiguous runs of `sorted`, staged with coalesced
+// loads together with the rows' cell_start slices; every lane then scans its own
+// cells out of LDS.  Queries the level-0 block does not settle (and workgroups
+// whose box does not fit) continue in global memory (knn_query).
 template <int QPT, bool WEIGHTED>
 __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
     const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
     const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
     const unsigned *__restrict__ cell_start, const float *__restrict__ pose32, int *__restrict__ nn_idx,
-    float *__restrict__ nn_sqd, double *__restrict__ partials, int nblk)
+    float *__restrict__ nn_sqd, unsigned *__restrict__ nn_pos, double *__restrict__ partials, int nblk,
+    int use_tile, int diag)
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
+    __shared__ float4 lpts[T_MAXP];
+    __shared__ unsigned lcs[T_MAXCS];
+    __shared__ unsigned rowg[T_MAXR];      // global position of the row's first staged point
+    __shared__ unsigned rowdelta[T_MAXR];  // rowg - (LDS offset of the row)
+    __shared__ int wbox[BLOCK / 64][6];
+    __shared__ unsigned s_total;
     __shared__ double wsum[BLOCK / 64][NACC];
+
     const int lb = xcd_remap(blockIdx.x, nblk);
     const int b = __builtin_amdgcn_readfirstlane(blk_pair[lb]);
     const int first = __builtin_amdgcn_readfirstlane(blk_first[lb]);
     const PairDesc &P = pairs[b];
+    const GridDesc &G0 = P.lv[0];
     const float *T = pose32 + (size_t)b * 12;
     const float r00 = T[0], r01 = T[1], r02 = T[2], tx = T[3];
     const float r10 = T[4], r11 = T[5], r12 = T[6], ty = T[7];
     const float r20 = T[8], r21 = T[9], r22 = T[10], tz = T[11];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     double acc[NACC];
 #pragma unroll
@@ -406,51 +511,173 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
 
 #pragma unroll 1
     for (int q = 0; q < QPT; ++q) {
-        int i = first + q * BLOCK + (int)threadIdx.x;
-        if (i >= P.n) continue;
-        float4 s = src4[P.src_off + i];
-        bool ok = finite3(s.x, s.y, s.z);
-        float px = __fmaf_rn(r00, s.x, __fmaf_rn(r01, s.y, __fmaf_rn(r02, s.z, tx)));
-        float py = __fmaf_rn(r10, s.x, __fmaf_rn(r11, s.y, __fmaf_rn(r12, s.z, ty)));
-        float pz = __fmaf_rn(r20, s.x, __fmaf_rn(r21, s.y, __fmaf_rn(r22, s.z, tz)));
-        Best<1> B;
-        B.init();
-        if (ok) knn_query<1>(P, sorted, cell_start, px, py, pz, B);
-        ok = ok && B.i[0] != 0x7fffffff;
-        nn_idx[P.src_off + i] = ok ? B.i[0] : -1;
-        nn_sqd[P.src_off + i] = ok ? B.d[0] : INFINITY;
-        if (!ok) continue;
-        float4 c = sorted[B.pos];
-        double dpx = px, dpy = py, dpz = pz, qx = c.x, qy = c.y, qz = c.z;
-        if (WEIGHTED) {
-            double w = wsrc[P.src_off + i], w2 = w * w;
-            acc[0] += w;
-            acc[1] += w * dpx; acc[2] += w * dpy; acc[3] += w * dpz;
-            acc[4] += w * qx;  acc[5] += w * qy;  acc[6] += w * qz;
-            double ax = w2 * dpx, ay = w2 * dpy, az = w2 * dpz;
-            acc[7] += ax * qx;  acc[8] += ax * qy;  acc[9] += ax * qz;
-            acc[10] += ay * qx; acc[11] += ay * qy; acc[12] += ay * qz;
-            acc[13] += az * qx; acc[14] += az * qy; acc[15] += az * qz;
-            acc[16] += sqrt((double)B.d[0]);
-            acc[17] += w2;
-            acc[18] += ax; acc[19] += ay; acc[20] += az;
-            acc[21] += w2 * qx; acc[22] += w2 * qy; acc[23] += w2 * qz;
-            acc[24] += 1.0;
-        } else {
-            acc[0] += 1.0;
-            acc[1] += dpx; acc[2] += dpy; acc[3] += dpz;
-            acc[4] += qx;  acc[5] += qy;  acc[6] += qz;
-            acc[7] += dpx * qx;  acc[8] += dpx * qy;  acc[9] += dpx * qz;
-            acc[10] += dpy * qx; acc[11] += dpy * qy; acc[12] += dpy * qz;
-            acc[13] += dpz * qx; acc[14] += dpz * qy; acc[15] += dpz * qz;
-            acc[16] += sqrt((double)B.d[0]);
+        const int i = first + q * BLOCK + (int)threadIdx.x;
+        const bool valid = i < P.n;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned wp = 0xffffffffu;
+        if (valid) {
+            s = src4[P.src_off + i];
+            wp = nn_pos[P.src_off + i];
         }
+        bool ok = valid && finite3(s.x, s.y, s.z);
+        const float px = __fmaf_rn(r00, s.x, __fmaf_rn(r01, s.y, __fmaf_rn(r02, s.z, tx)));
+        const float py = __fmaf_rn(r10, s.x, __fmaf_rn(r11, s.y, __fmaf_rn(r12, s.z, ty)));
+        const float pz = __fmaf_rn(r20, s.x, __fmaf_rn(r21, s.y, __fmaf_rn(r22, s.z, tz)));
+        BestQ B;
+        B.init();
+        // warm start: last iteration's neighbour is a valid candidate and usually still
+        // the nearest, which lets the row/cell bounds prune almost everything
+        float4 wc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && wp != 0xffffffffu) wc = sorted[wp];
+        CellGeo C;
+        C.set(G0, px, py, pz);
+
+        // ---- workgroup box of level-0 cells
+        bool tiled = use_tile != 0;
+        int bx0 = 0, by0 = 0, bz0 = 0, W = 0, NYb = 0;
+        if (tiled) {  // uniform
+            int v[6] = {ok ? C.cx : 0x7fffffff, ok ? C.cy : 0x7fffffff, ok ? C.cz : 0x7fffffff,
+                        ok ? -C.cx : 0x7fffffff, ok ? -C.cy : 0x7fffffff, ok ? -C.cz : 0x7fffffff};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                v[k] = wave_min(v[k]);
+                if (lane == 0) wbox[wave][k] = v[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                int m = wbox[0][k];
+#pragma unroll
+                for (int w = 1; w < BLOCK / 64; ++w) m = min(m, wbox[w][k]);
+                v[k] = m;
+            }
+            if (v[0] == 0x7fffffff) {
+                tiled = false;  // no usable query in this batch
+            } else {
+                bx0 = max(v[0] - 1, 0);
+                by0 = max(v[1] - 1, 0);
+                bz0 = max(v[2] - 1, 0);
+                const int bx1 = min(-v[3] + 1, G0.nx - 1), by1 = min(-v[4] + 1, G0.ny - 1),
+                          bz1 = min(-v[5] + 1, G0.nz - 1);
+                W = bx1 - bx0 + 1;
+                NYb = by1 - by0 + 1;
+                const int NR = NYb * (bz1 - bz0 + 1);
+                tiled = NR <= T_MAXR && NR * (W + 1) <= T_MAXCS;
+                if (tiled) {
+                    // stage the rows' cell_start slices: cells bx0 .. bx1+1 of every row
+                    const int total = NR * (W + 1);
+                    for (int e = threadIdx.x; e < total; e += BLOCK) {
+                        const int r = e / (W + 1), k = e - r * (W + 1);
+                        const int rz = r / NYb, ry = r - rz * NYb;
+                        lcs[e] = cell_start[G0.cell_base + ((long long)(bz0 + rz) * G0.ny + (by0 + ry)) * G0.nx + bx0 + k];
+                    }
+                    __syncthreads();
+                    if (wave == 0) {
+                        // per-row point counts -> LDS offsets (exclusive scan over <= 96 rows)
+                        unsigned run = 0;
+                        for (int r0 = 0; r0 < NR; r0 += 64) {
+                            const int r = r0 + lane;
+                            unsigned g = 0, cnt = 0;
+                            if (r < NR) {
+                                g = lcs[r * (W + 1)];
+                                cnt = lcs[r * (W + 1) + W] - g;
+                            }
+                            unsigned inc = cnt;
+#pragma unroll
+                            for (int sft = 1; sft < 64; sft <<= 1) {
+                                unsigned t = __shfl_up(inc, sft);
+                                if (lane >= sft) inc += t;
+                            }
+                            if (r < NR) {
+                                rowg[r] = g;
+                                rowdelta[r] = g - (run + inc - cnt);
+                            }
+                            run += __shfl(inc, 63);
+                        }
+                        if (lane == 0) s_total = run;
+                    }
+                    __syncthreads();
+                    tiled = s_total <= (unsigned)T_MAXP;
+                    if (tiled) {
+                        for (int r = 0; r < NR; ++r) {
+                            const unsigned g = rowg[r], cnt = lcs[r * (W + 1) + W] - g, dl = rowdelta[r];
+                            for (unsigned k = threadIdx.x; k < cnt; k += BLOCK) lpts[g + k - dl] = sorted[g + k];
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+
+        if (ok) {
+            if (wp != 0xffffffffu) B.consider(sqdist(px, py, pz, wc.x, wc.y, wc.z), wc, wp);
+            int next_level = 0;
+            if (tiled) {
+                const float mg = G0.margin;
+                const float bxl = fmaxf(C.fx0 - mg, 0.f), bxr = fmaxf(C.fx1 - mg, 0.f);
+                const bool has_l = C.cx > 0, has_r = C.cx + 1 < G0.nx;
+#pragma unroll 1
+                for (int r = 0; r < 9; ++r) {
+                    const int kz = r / 3, ky = r - 3 * kz;
+                    const int dz = kz == 0 ? 0 : (kz == 1 ? -1 : 1);
+                    const int dy = ky == 0 ? 0 : (ky == 1 ? -1 : 1);
+                    const int zz = C.cz + dz, yy = C.cy + dy;
+                    if (zz < 0 || zz >= G0.nz || yy < 0 || yy >= G0.ny) continue;
+                    const float bz = dz == 0 ? 0.f : fmaxf((dz < 0 ? C.fz0 : C.fz1) - mg, 0.f);
+                    const float by = dy == 0 ? 0.f : fmaxf((dy < 0 ? C.fy0 : C.fy1) - mg, 0.f);
+                    const float rb2 = by * by + bz * bz;
+                    if (rb2 * 0.99999f > B.worst()) continue;
+                    const int lr = (zz - bz0) * NYb + (yy - by0);
+                    const int e = lr * (W + 1) + (C.cx - bx0);
+                    const unsigned c1 = lcs[e], c2 = lcs[e + 1];
+                    const unsigned c0 = has_l ? lcs[e - 1] : c1, c3 = has_r ? lcs[e + 2] : c2;
+                    const unsigned dl = rowdelta[lr];
+                    scan_run_lds(B, lpts, c1, c2, dl, px, py, pz);
+                    if (c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst()) scan_run_lds(B, lpts, c0, c1, dl, px, py, pz);
+                    if (c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst()) scan_run_lds(B, lpts, c2, c3, dl, px, py, pz);
+                }
+                next_level = B.worst() <= C.settled_r2(G0) ? P.nlevels : 1;
+            }
+            if (next_level < P.nlevels && !(diag & 1)) knn_query(P, sorted, cell_start, px, py, pz, B, next_level);
+        }
+        ok = ok && B.i != 0x7fffffff;
+        if (valid) {
+            nn_idx[P.src_off + i] = ok ? B.i : -1;
+            nn_sqd[P.src_off + i] = ok ? B.d : INFINITY;
+            nn_pos[P.src_off + i] = ok ? B.pos : 0xffffffffu;
+        }
+        if (ok) {
+            const double dpx = px, dpy = py, dpz = pz, qx = B.x, qy = B.y, qz = B.z;
+            if (WEIGHTED) {
+                const double w = wsrc[P.src_off + i], w2 = w * w;
+                acc[0] += w;
+                acc[1] += w * dpx; acc[2] += w * dpy; acc[3] += w * dpz;
+                acc[4] += w * qx;  acc[5] += w * qy;  acc[6] += w * qz;
+                const double ax = w2 * dpx, ay = w2 * dpy, az = w2 * dpz;
+                acc[7] += ax * qx;  acc[8] += ax * qy;  acc[9] += ax * qz;
+                acc[10] += ay * qx; acc[11] += ay * qy; acc[12] += ay * qz;
+                acc[13] += az * qx; acc[14] += az * qy; acc[15] += az * qz;
+                acc[16] += sqrt((double)B.d);
+                acc[17] += w2;
+                acc[18] += ax; acc[19] += ay; acc[20] += az;
+                acc[21] += w2 * qx; acc[22] += w2 * qy; acc[23] += w2 * qz;
+                acc[24] += 1.0;
+            } else {
+                acc[0] += 1.0;
+                acc[1] += dpx; acc[2] += dpy; acc[3] += dpz;
+                acc[4] += qx;  acc[5] += qy;  acc[6] += qz;
+                acc[7] += dpx * qx;  acc[8] += dpx * qy;  acc[9] += dpx * qz;
+                acc[10] += dpy * qx; acc[11] += dpy * qy; acc[12] += dpy * qz;
+                acc[13] += dpz * qx; acc[14] += dpz * qy; acc[15] += dpz * qz;
+                acc[16] += sqrt((double)B.d);
+            }
+        }
+        if (QPT > 1) __syncthreads();  // the tile is re-staged by the next batch
     }
     // wave shuffle reduction, then the 4 wave totals through LDS (fixed order)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
-        double v = wave_sum(acc[k]);
+        double v = (diag & 2) ? acc[k] : wave_sum(acc[k]);
         if (lane == 0) wsum[wave][k] = v;
     }
     __syncthreads();
@@ -484,7 +711,7 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const PairDesc *__restric
     }
 #pragma unroll
     for (int k = 0; k < NACC; ++k) a[k] = wave_sum(a[k]);
-    if (lane != 0) return;
+    if (lane != 0) return;  // wave_sum leaves the totals in every lane
 
     const double sw = a[0];
     double *T = pose64 + (size_t)b * 16;
@@ -574,7 +801,8 @@ struct GridSet {
     DevBuf<PairDesc> pairs;
     DevBuf<float4> pts4;    // caller order
     DevBuf<float4> sorted;  // all (pair, level) blocks
-    DevBuf<unsigned> cell_start;
+    DevBuf<unsigned> cell_start_buf;  // 4 pad + cells + 1 + 4 pad
+    unsigned *cell_start = nullptr;
     long long total_cells = 0, total_sorted = 0;
 };
 
@@ -628,7 +856,7 @@ static void plan_levels(const float mn[3], const float mx[3], int m, float cell,
         G.nz = (int)std::floor(ext[2] / h) + 1;
         // slack for the float rounding of cell assignment vs. face positions
         G.margin = 1e-4f * h + 16.0f * 1.1920929e-7f * (amax + emax);
-        G.pad = 0;
+        G.tile = max_levels == 1 ? 1 : 0;
         h *= ratio;
     }
 }
@@ -691,7 +919,8 @@ static int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long 
         plan_levels(mn, mx, P.m, cell, max_levels, P);
         for (int l = 0; l < P.nlevels; ++l) {
             P.lv[l].cell_base = cells;
-            cells += (long long)P.lv[l].nx * P.lv[l].ny * P.lv[l].nz;
+            const GridDesc &G = P.lv[l];
+            cells += G.tile ? (long long)G.nz * ((G.ny + 7) / 8) * ((G.nx + 7) / 8) * 64 : (long long)G.nx * G.ny * G.nz;
             sorted_total += P.m;
         }
     }
@@ -703,20 +932,22 @@ static int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long 
                                    ctx->stream));
     DevBuf<unsigned> counts;
     GPSCAL_HIP(ctx, counts.alloc((size_t)cells + 1));
-    GPSCAL_HIP(ctx, gs.cell_start.alloc((size_t)cells + 1));
+    GPSCAL_HIP(ctx, gs.cell_start_buf.alloc((size_t)cells + 1 + 8));
+    GPSCAL_HIP(ctx, hipMemsetAsync(gs.cell_start_buf.p, 0, sizeof(unsigned) * ((size_t)cells + 9), ctx->stream));
+    gs.cell_start = gs.cell_start_buf.p + 4;
     GPSCAL_HIP(ctx, gs.sorted.alloc((size_t)sorted_total));
     GPSCAL_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
     if (npairs > 0 && mmax > 0) {
         int gxf = std::max(1, std::min(div_up(mmax, BLOCK), 1024));
         hipLaunchKernelGGL(grid_fill_kernel<0>, dim3(gxf, npairs), dim3(BLOCK), 0, ctx->stream, gs.pairs.p,
                            gs.pts4.p, counts.p, (const unsigned *)nullptr, (float4 *)nullptr);
-        int rc = exclusive_scan(ctx, counts.p, gs.cell_start.p, cells + 1);
+        int rc = exclusive_scan(ctx, counts.p, gs.cell_start, cells + 1);
         if (rc) return rc;
         GPSCAL_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
         hipLaunchKernelGGL(grid_fill_kernel<1>, dim3(gxf, npairs), dim3(BLOCK), 0, ctx->stream, gs.pairs.p,
-                           gs.pts4.p, counts.p, gs.cell_start.p, gs.sorted.p);
+                           gs.pts4.p, counts.p, gs.cell_start, gs.sorted.p);
     } else {
-        GPSCAL_HIP(ctx, hipMemsetAsync(gs.cell_start.p, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
+        GPSCAL_HIP(ctx, hipMemsetAsync(gs.cell_start, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
     }
     GPSCAL_HIP(ctx, hipGetLastError());
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -739,7 +970,7 @@ struct gpscal_scan_batch {
     int npairs = 0;
     long long total_n = 0;
     bool weighted = false;
-    int qpt = 1, nblk = 0;
+    int qpt = 1, nblk = 0, use_tile = 1, diag = 0;
     DevBuf<PairDesc> pairs;  // target descs + source fields
     std::vector<PairDesc> hpairs;
     DevBuf<float4> src4;
@@ -747,6 +978,7 @@ struct gpscal_scan_batch {
     DevBuf<int> blk_pair, blk_first;
     DevBuf<int> nn_idx;
     DevBuf<float> nn_sqd;
+    DevBuf<unsigned> nn_pos;  // warm start: position of last iteration's neighbour in `sorted`
     DevBuf<double> partials, pose64, err_hist;
     DevBuf<float> pose32;
     int err_cap = 0;
@@ -791,7 +1023,7 @@ template <int K>
 static void launch_search(gpscal_ctx *ctx, GridSet &gs, const char *q, int stride, int n, int *idx, float *sqd)
 {
     hipLaunchKernelGGL(knn_search_kernel<K>, dim3(div_up(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, gs.pairs.p,
-                       gs.sorted.p, gs.cell_start.p, q, stride, n, idx, sqd);
+                       gs.sorted.p, gs.cell_start, q, stride, n, idx, sqd);
 }
 
 extern "C" int gpscal_knn_search(gpscal_knn_index *index, const float *query, int n, int stride_bytes, int k,
@@ -852,7 +1084,7 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
     std::vector<unsigned> ends(np);
     for (int b = 0; b < np; ++b) {
         long long endcell = (b + 1 < np) ? sg.hpairs[b + 1].lv[0].cell_base : sg.total_cells;
-        GPSCAL_HIP(ctx, hipMemcpyAsync(&ends[b], sg.cell_start.p + endcell, sizeof(unsigned), hipMemcpyDeviceToHost,
+        GPSCAL_HIP(ctx, hipMemcpyAsync(&ends[b], sg.cell_start + endcell, sizeof(unsigned), hipMemcpyDeviceToHost,
                                        ctx->stream));
     }
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -868,7 +1100,11 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
                                    hipMemcpyDeviceToDevice, ctx->stream));
     // block table
     const long long per_blk_target = (long long)ctx->prop.multiProcessorCount * 8 * BLOCK;
-    B->qpt = B->total_n >= 4 * per_blk_target ? 4 : 1;
+    (void)per_blk_target;
+    B->qpt = 1;  // one batch per workgroup keeps the tiled kernel at 78 VGPRs
+    if (const char *e = getenv("GPSCAL_QPT")) B->qpt = atoi(e) == 4 ? 4 : 1;  // tuning knobs
+    if (const char *e = getenv("GPSCAL_TILE")) B->use_tile = atoi(e) != 0;
+    if (const char *e = getenv("GPSCAL_DIAG")) B->diag = atoi(e);  // ablation (wrong results!)
     std::vector<int> bp, bf;
     for (int b = 0; b < np; ++b) {
         PairDesc &P = B->hpairs[b];
@@ -901,6 +1137,8 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
     }
     GPSCAL_HIP(ctx, B->nn_idx.alloc((size_t)std::max<long long>(B->total_n, 1)));
     GPSCAL_HIP(ctx, B->nn_sqd.alloc((size_t)std::max<long long>(B->total_n, 1)));
+    GPSCAL_HIP(ctx, B->nn_pos.alloc((size_t)std::max<long long>(B->total_n, 1)));
+    GPSCAL_HIP(ctx, hipMemsetAsync(B->nn_pos.p, 0xff, sizeof(unsigned) * (size_t)std::max<long long>(B->total_n, 1), ctx->stream));
     GPSCAL_HIP(ctx, B->partials.alloc((size_t)std::max(B->nblk, 1) * NACC_WEIGHTED));
     GPSCAL_HIP(ctx, B->pose64.alloc((size_t)np * 16));
     GPSCAL_HIP(ctx, B->pose32.alloc((size_t)np * 12));
@@ -960,8 +1198,8 @@ static void launch_step(gpscal_scan_batch *B)
     if (B->nblk == 0) return;
 #define STEP(QPT, W)                                                                                         \
     hipLaunchKernelGGL((icp_step_kernel<QPT, W>), dim3(B->nblk), dim3(BLOCK), 0, ctx->stream, B->pairs.p,     \
-                       B->blk_pair.p, B->blk_first.p, B->src4.p, B->wsorted.p, G.sorted.p, G.cell_start.p,     \
-                       B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->partials.p, B->nblk)
+                       B->blk_pair.p, B->blk_first.p, B->src4.p, B->wsorted.p, G.sorted.p, G.cell_start,     \
+                       B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->nn_pos.p, B->partials.p, B->nblk, B->use_tile, B->diag)
     if (B->weighted) {
         if (B->qpt == 4) STEP(4, true); else STEP(1, true);
     } else {

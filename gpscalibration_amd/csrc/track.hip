@@ -18,6 +18,7 @@
 // Per-segment traffic: 5*8*N bytes in, <= 9*8*N out: negligible; the
 // kernel is latency/sync-bound, so the lever is one launch for ALL segments.
 #include "common.hpp"
+#include "wave_reduce.hpp"
 
 #include <algorithm>
 
@@ -33,9 +34,7 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double (*red)[8])
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        double x = v[k];
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s);
+        double x = wave_sum(v[k]);
         if (lane == 0) red[wave][k] = x;
     }
     __syncthreads();
