@@ -255,6 +255,7 @@ static int exclusive_scan(gpscal_ctx *ctx, const unsigned *in, unsigned *out, lo
 
 template <int K>
 struct Best {
+    static constexpr bool COOP = false;  // k > 1: per-lane scanning only
     float d[K];
     int i[K];
     __device__ __forceinline__ void init()
@@ -294,6 +295,7 @@ struct Best {
 // 1-NN record of the ICP kernel: keeps the neighbour's coordinates (no second
 // gather) and its position in `sorted` (next iteration's warm start).
 struct BestQ {
+    static constexpr bool COOP = true;  // long runs are scanned by the whole wave
     float d;
     int i;
     unsigned pos;
@@ -325,11 +327,13 @@ struct __attribute__((packed, aligned(4))) CellQuad {
     unsigned a, b, c, d;
 };
 
-// Candidates [s, e) of `sorted` in HBM/L2, four 16-byte loads in flight per lane.
+// Candidates [s, e) of `sorted`, scanned by the lane itself with four 16-byte
+// gathers in flight.
 template <class BT>
-__device__ __forceinline__ void scan_run(BT &B, const float4 *__restrict__ sorted, unsigned s, unsigned e,
-                                         float px, float py, float pz)
+__device__ __forceinline__ void scan_short(BT &B, bool act, const float4 *__restrict__ sorted, unsigned s, unsigned e,
+                                           float px, float py, float pz)
 {
+    if (!act) return;
     for (unsigned j = s; j < e; j += 4) {
         const unsigned last = e - 1;
         float4 c0 = sorted[j];
@@ -343,16 +347,58 @@ __device__ __forceinline__ void scan_run(BT &B, const float4 *__restrict__ sorte
     }
 }
 
-// Same over the LDS-staged tile: global position j lives at lpts[j - delta].
-template <class BT>
-__device__ __forceinline__ void scan_run_lds(BT &B, const float4 *lpts, unsigned s, unsigned e, unsigned delta,
-                                             float px, float py, float pz)
+constexpr unsigned COOP_MIN = 12;  // runs longer than this are scanned by the whole wave
+
+__device__ __forceinline__ float readlane_f(float v, int l)
 {
-    for (unsigned j = s; j < e; j += 2) {
-        float4 c0 = lpts[j - delta];
-        float4 c1 = lpts[min(j + 1, e - 1) - delta];
-        B.consider(sqdist(px, py, pz, c0.x, c0.y, c0.z), c0, j);
-        if (j + 1 < e) B.consider(sqdist(px, py, pz, c1.x, c1.y, c1.z), c1, j + 1);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// Must be reached by all 64 lanes of the wave (wave-uniform control flow).  Short
+// runs are scanned per lane.  A long run (a dense or coarse cell) is scanned by the
+// whole wave for its owner: 64 consecutive candidates per step, one coalesced 1 KiB
+// load instead of 64 dependent gathers by one lane, then a DPP arg-min.
+template <class BT>
+__device__ __forceinline__ void scan_runs(BT &B, bool act, const float4 *__restrict__ sorted, unsigned s, unsigned e,
+                                          float px, float py, float pz)
+{
+    if constexpr (!BT::COOP) {
+        scan_short(B, act, sorted, s, e, px, py, pz);
+    } else {
+        const bool lng = act && (e - s) > COOP_MIN;
+        scan_short(B, act && !lng, sorted, s, e, px, py, pz);
+        unsigned long long m = __ballot(lng);
+        const int lane = threadIdx.x & 63;
+        while (m) {  // wave-uniform
+            const int owner = __builtin_ctzll(m);
+            m &= m - 1;
+            const float qx = readlane_f(px, owner), qy = readlane_f(py, owner), qz = readlane_f(pz, owner);
+            const unsigned ss = __builtin_amdgcn_readlane(s, owner), ee = __builtin_amdgcn_readlane(e, owner);
+            float bd = INFINITY;
+            int bi = 0x7fffffff;
+            unsigned bp = 0;
+            float bx = 0.f, by = 0.f, bz = 0.f;
+            for (unsigned j0 = ss; j0 < ee; j0 += 64) {
+                const unsigned j = j0 + lane;
+                if (j < ee) {
+                    const float4 c = sorted[j];
+                    const float d2 = sqdist(qx, qy, qz, c.x, c.y, c.z);
+                    const int ci = __float_as_int(c.w);
+                    if (d2 < bd || (d2 == bd && ci < bi)) {
+                        bd = d2; bi = ci; bp = j; bx = c.x; by = c.y; bz = c.z;
+                    }
+                }
+            }
+            // (d2 >= 0, index >= 0): the 64-bit key orders exactly like (d2, index)
+            const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bi;
+            const unsigned long long kmin = wave_min_u64(key);
+            const int win = __builtin_ctzll(__ballot(key == kmin));
+            const float wd = readlane_f(bd, win);
+            const float4 wc = make_float4(readlane_f(bx, win), readlane_f(by, win), readlane_f(bz, win),
+                                          __int_as_float(__builtin_amdgcn_readlane(bi, win)));
+            const unsigned wpos = __builtin_amdgcn_readlane(bp, win);
+            if (lane == owner && wd < INFINITY) B.consider(wd, wc, wpos);
+        }
     }
 }
 
@@ -386,55 +432,54 @@ struct CellGeo {
     }
 };
 
-// One level of the search out of global memory.
-template <class BT>
-__device__ __forceinline__ void knn_level_global(const GridDesc &G, const CellGeo &C, const float4 *__restrict__ sorted,
-                                                 const unsigned *__restrict__ cell_start, float px, float py,
-                                                 float pz, BT &B)
-{
-    const float mg = G.margin;
-    const float bxl = fmaxf(C.fx0 - mg, 0.f), bxr = fmaxf(C.fx1 - mg, 0.f);
-    const bool has_l = C.cx > 0, has_r = C.cx + 1 < G.nx;
-#pragma unroll 1
-    for (int r = 0; r < 9; ++r) {
-        const int kz = r / 3, ky = r - 3 * kz;
-        const int dz = kz == 0 ? 0 : (kz == 1 ? -1 : 1);
-        const int dy = ky == 0 ? 0 : (ky == 1 ? -1 : 1);
-        const int zz = C.cz + dz, yy = C.cy + dy;
-        if (zz < 0 || zz >= G.nz || yy < 0 || yy >= G.ny) continue;
-        const float bz = dz == 0 ? 0.f : fmaxf((dz < 0 ? C.fz0 : C.fz1) - mg, 0.f);
-        const float by = dy == 0 ? 0.f : fmaxf((dy < 0 ? C.fy0 : C.fy1) - mg, 0.f);
-        const float rb2 = by * by + bz * bz;
-        if (rb2 * 0.99999f > B.worst()) continue;  // row cannot hold a better point
-        const long long row = G.cell_base + ((long long)zz * G.ny + yy) * G.nx + C.cx;
-        // cell_start[row-1 .. row+2]: left | own | right cell boundaries
-        const CellQuad q = *reinterpret_cast<const CellQuad *>(cell_start + row - 1);
-        const unsigned c0 = has_l ? q.a : q.b, c1 = q.b, c2 = q.c, c3 = has_r ? q.d : q.c;
-        scan_run(B, sorted, c1, c2, px, py, pz);
-        if (c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst()) scan_run(B, sorted, c0, c1, px, py, pz);
-        if (c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst()) scan_run(B, sorted, c2, c3, px, py, pz);
-    }
-}
-
-// Exact k-NN of (px,py,pz) in pair P, levels first_level.. fine -> coarse.  A
-// level's 3x3x3 block of cells settles the query when the k-th best distance is
-// within the distance to the nearest face of the block that still has cells
-// behind it.  The coarsest level has <= 2 cells per axis, so it always settles.
-// Rows (fixed y,z; x-1..x+1 contiguous in memory) and then single cells are
-// skipped when their nearest face is already farther than the k-th best, so a
-// good starting candidate (the previous iteration's neighbour) removes most of
-// the memory traffic.
+// Exact k-NN of (px,py,pz) in pair P, levels first_level.. fine -> coarse.  MUST be
+// called by all 64 lanes of a wave (act = false for lanes without a query): control
+// flow is wave-uniform so that long runs can be scanned cooperatively.
+// A level's 3x3x3 block of cells settles the query when the k-th best distance is
+// within the distance to the nearest face of the block that still has cells behind
+// it.  The coarsest level has <= 2 cells per axis, so it always settles.  Rows
+// (fixed y,z; x-1..x+1 contiguous in memory) and then single cells are skipped when
+// their nearest face is already farther than the k-th best, so a good starting
+// candidate (the previous iteration's neighbour) removes most of the memory traffic.
 template <class BT>
 __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__restrict__ sorted,
-                                          const unsigned *__restrict__ cell_start, float px, float py, float pz,
-                                          BT &B, int first_level = 0)
+                                          const unsigned *__restrict__ cell_start, bool act, float px, float py,
+                                          float pz, BT &B, int first_level = 0)
 {
+    if (!act) px = py = pz = 0.f;
     for (int l = first_level; l < P.nlevels; ++l) {
+        if (__ballot(act) == 0ull) break;
         const GridDesc &G = P.lv[l];
         CellGeo C;
         C.set(G, px, py, pz);
-        knn_level_global(G, C, sorted, cell_start, px, py, pz, B);
-        if (B.worst() <= C.settled_r2(G)) break;
+        const float mg = G.margin;
+        const float bxl = fmaxf(C.fx0 - mg, 0.f), bxr = fmaxf(C.fx1 - mg, 0.f);
+        const bool has_l = C.cx > 0, has_r = C.cx + 1 < G.nx;
+#pragma unroll 1
+        for (int r = 0; r < 9; ++r) {
+            const int kz = r / 3, ky = r - 3 * kz;
+            const int dz = kz == 0 ? 0 : (kz == 1 ? -1 : 1);
+            const int dy = ky == 0 ? 0 : (ky == 1 ? -1 : 1);
+            const int zz = C.cz + dz, yy = C.cy + dy;
+            const float bz = dz == 0 ? 0.f : fmaxf((dz < 0 ? C.fz0 : C.fz1) - mg, 0.f);
+            const float by = dy == 0 ? 0.f : fmaxf((dy < 0 ? C.fy0 : C.fy1) - mg, 0.f);
+            const float rb2 = by * by + bz * bz;
+            const bool pass = act && zz >= 0 && zz < G.nz && yy >= 0 && yy < G.ny && rb2 * 0.99999f <= B.worst();
+            if (__ballot(pass) == 0ull) continue;  // no lane of the wave needs this row
+            unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            if (pass) {
+                const long long row = G.cell_base + ((long long)zz * G.ny + yy) * G.nx + C.cx;
+                // cell_start[row-1 .. row+2]: left | own | right cell boundaries
+                const CellQuad q = *reinterpret_cast<const CellQuad *>(cell_start + row - 1);
+                c0 = has_l ? q.a : q.b; c1 = q.b; c2 = q.c; c3 = has_r ? q.d : q.c;
+            }
+            scan_runs(B, pass, sorted, c1, c2, px, py, pz);
+            const bool pl = pass && c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst();
+            const bool pr = pass && c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst();
+            if (__ballot(pl) != 0ull) scan_runs(B, pl, sorted, c0, c1, px, py, pz);
+            if (__ballot(pr) != 0ull) scan_runs(B, pr, sorted, c2, c3, px, py, pz);
+        }
+        if (act && B.worst() <= C.settled_r2(G)) act = false;
     }
 }
 
@@ -446,14 +491,17 @@ __global__ __launch_bounds__(BLOCK) void knn_search_kernel(const PairDesc *__res
                                                             const char *__restrict__ qraw, int stride, int n,
                                                             int *__restrict__ idx, float *__restrict__ sqd)
 {
-    int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
     const PairDesc &P = pairs[0];
-    const float *q = reinterpret_cast<const float *>(qraw + (size_t)i * stride);
-    float px = q[0], py = q[1], pz = q[2];
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (i < n) {
+        const float *q = reinterpret_cast<const float *>(qraw + (size_t)i * stride);
+        px = q[0]; py = q[1]; pz = q[2];
+    }
     Best<K> B;
     B.init();
-    if (finite3(px, py, pz)) knn_query(P, sorted, cell_start, px, py, pz, B);
+    knn_query(P, sorted, cell_start, i < n && finite3(px, py, pz), px, py, pz, B);
+    if (i >= n) return;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         bool ok = B.i[k] != 0x7fffffff;
@@ -462,43 +510,79 @@ __global__ __launch_bounds__(BLOCK) void knn_search_kernel(const PairDesc *__res
     }
 }
 
-// ---- LDS tile limits of the fused kernel (bytes: 16*MAXP + 4*MAXCS + small)
-constexpr int T_MAXP = 1536;   // staged target points
-constexpr int T_MAXCS = 1536;  // staged cell_start entries
-constexpr int T_MAXR = 96;     // rows (y,z) of the staged box
+// Self-neighbour pass of the index build: for every target point the squared
+// distance to its nearest OTHER point (second of a k=2 search at its own position).
+__global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restrict__ pairs,
+                                                         const float4 *__restrict__ sorted,
+                                                         const unsigned *__restrict__ cell_start,
+                                                         float *__restrict__ d2nn)
+{
+    const int b = blockIdx.y;
+    const PairDesc &P = pairs[b];
+    // level-0 block of this pair = positions [first0, end0)
+    const unsigned first0 = cell_start[P.lv[0].cell_base];
+    const unsigned end0 = cell_start[P.lv[0].cell_base + (long long)P.lv[0].nx * P.lv[0].ny * P.lv[0].nz];
+    for (unsigned j0 = first0 + blockIdx.x * BLOCK; j0 < end0; j0 += gridDim.x * BLOCK) {
+        const unsigned j = j0 + threadIdx.x;
+        const bool act = j < end0;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) c = sorted[j];
+        Best<2> B;
+        B.init();
+        knn_query(P, sorted, cell_start, act, c.x, c.y, c.z, B);
+        if (act) d2nn[P.tgt_off + __float_as_int(c.w)] = B.d[1];  // +inf for a single-point cloud
+    }
+}
+
+// safe_r2[pos]: if a query is closer than this (squared) to sorted[pos], that point
+// is certainly its unique nearest neighbour: with r = half the distance from the
+// point to its own nearest neighbour, |p-q| < r implies |p-q'| >= 2r - |p-q| > |p-q|
+// for every other q'.  The 0.99 factor absorbs float rounding of all three distances.
+__global__ void safe_radius_kernel(const float4 *__restrict__ sorted, const float *__restrict__ d2nn,
+                                   const PairDesc *__restrict__ pairs, int npairs,
+                                   const unsigned *__restrict__ cell_start, float *__restrict__ safe_r2,
+                                   long long total_sorted)
+{
+    long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= total_sorted) return;
+    // pair owning this position: last b whose first level-0 position is <= pos
+    int lo = 0, hi = npairs;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if ((long long)cell_start[pairs[mid].lv[0].cell_base] <= pos) lo = mid; else hi = mid;
+    }
+    const float d2 = d2nn[pairs[lo].tgt_off + __float_as_int(sorted[pos].w)];
+    safe_r2[pos] = isfinite(d2) ? 0.25f * 0.99f * d2 : 3.0e38f;
+}
 
 // The fused ICP correspondence kernel: transform -> exact 1-NN -> weighted
-// centroid / covariance partials.  One lane per source point, 256 consecutive
-// points of the spatially grouped source per workgroup (QPT batches of 256).
+// centroid / covariance partials.  One lane per source point, QPT batches of 256
+// consecutive points of the spatially grouped source per workgroup.
 //
-// Level 0 of the search runs out of LDS: the workgroup's queries are spatially
-// coherent, so the union of their 3x3x3 cell blocks is a small box of the
-// target grid.  Its rows are contiguous runs of `sorted`, staged with coalesced
-// loads together with the rows' cell_start slices; every lane then scans its own
-// cells out of LDS.  Queries the level-0 block does not settle (and workgroups
-// whose box does not fit) continue in global memory (knn_query).
+// Per query, cheapest test first:
+//   1. warm start: last iteration's neighbour (one 16-byte gather + its safe radius);
+//      inside the safe radius it is PROVEN to be the nearest neighbour: no search;
+//   2. otherwise the multi-level grid search, seeded with that candidate so the row
+//      and cell bounds prune most of the 3x3x3 block; long runs of candidates are
+//      scanned by the whole wave (scan_runs).
+// An LDS-staged variant of level 0 (workgroup box of cells copied to LDS) was built
+// and measured SLOWER than this pruned global path (the box holds ~3.3 points per
+// query against ~2.4 the query reads); see DESIGN.md.
 template <int QPT, bool WEIGHTED>
 __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
     const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
     const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
-    const unsigned *__restrict__ cell_start, const float *__restrict__ pose32, int *__restrict__ nn_idx,
-    float *__restrict__ nn_sqd, unsigned *__restrict__ nn_pos, double *__restrict__ partials, int nblk,
-    int use_tile, int diag)
+    const float *__restrict__ safe_r2, const unsigned *__restrict__ cell_start, const float *__restrict__ pose32,
+    int *__restrict__ nn_idx, float *__restrict__ nn_sqd, unsigned *__restrict__ nn_pos,
+    double *__restrict__ partials, int nblk, int diag)
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
-    __shared__ float4 lpts[T_MAXP];
-    __shared__ unsigned lcs[T_MAXCS];
-    __shared__ unsigned rowg[T_MAXR];      // global position of the row's first staged point
-    __shared__ unsigned rowdelta[T_MAXR];  // rowg - (LDS offset of the row)
-    __shared__ int wbox[BLOCK / 64][6];
-    __shared__ unsigned s_total;
     __shared__ double wsum[BLOCK / 64][NACC];
 
     const int lb = xcd_remap(blockIdx.x, nblk);
     const int b = __builtin_amdgcn_readfirstlane(blk_pair[lb]);
     const int first = __builtin_amdgcn_readfirstlane(blk_first[lb]);
     const PairDesc &P = pairs[b];
-    const GridDesc &G0 = P.lv[0];
     const float *T = pose32 + (size_t)b * 12;
     const float r00 = T[0], r01 = T[1], r02 = T[2], tx = T[3];
     const float r10 = T[4], r11 = T[5], r12 = T[6], ty = T[7];
@@ -525,156 +609,47 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
         const float pz = __fmaf_rn(r20, s.x, __fmaf_rn(r21, s.y, __fmaf_rn(r22, s.z, tz)));
         BestQ B;
         B.init();
-        // warm start: last iteration's neighbour is a valid candidate and usually still
-        // the nearest, which lets the row/cell bounds prune almost everything
-        float4 wc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && wp != 0xffffffffu) wc = sorted[wp];
-        CellGeo C;
-        C.set(G0, px, py, pz);
-
-        // ---- workgroup box of level-0 cells
-        bool tiled = use_tile != 0;
-        int bx0 = 0, by0 = 0, bz0 = 0, W = 0, NYb = 0;
-        if (tiled) {  // uniform
-            int v[6] = {ok ? C.cx : 0x7fffffff, ok ? C.cy : 0x7fffffff, ok ? C.cz : 0x7fffffff,
-                        ok ? -C.cx : 0x7fffffff, ok ? -C.cy : 0x7fffffff, ok ? -C.cz : 0x7fffffff};
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                v[k] = wave_min(v[k]);
-                if (lane == 0) wbox[wave][k] = v[k];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                int m = wbox[0][k];
-#pragma unroll
-                for (int w = 1; w < BLOCK / 64; ++w) m = min(m, wbox[w][k]);
-                v[k] = m;
-            }
-            if (v[0] == 0x7fffffff) {
-                tiled = false;  // no usable query in this batch
-            } else {
-                bx0 = max(v[0] - 1, 0);
-                by0 = max(v[1] - 1, 0);
-                bz0 = max(v[2] - 1, 0);
-                const int bx1 = min(-v[3] + 1, G0.nx - 1), by1 = min(-v[4] + 1, G0.ny - 1),
-                          bz1 = min(-v[5] + 1, G0.nz - 1);
-                W = bx1 - bx0 + 1;
-                NYb = by1 - by0 + 1;
-                const int NR = NYb * (bz1 - bz0 + 1);
-                tiled = NR <= T_MAXR && NR * (W + 1) <= T_MAXCS;
-                if (tiled) {
-                    // stage the rows' cell_start slices: cells bx0 .. bx1+1 of every row
-                    const int total = NR * (W + 1);
-                    for (int e = threadIdx.x; e < total; e += BLOCK) {
-                        const int r = e / (W + 1), k = e - r * (W + 1);
-                        const int rz = r / NYb, ry = r - rz * NYb;
-                        lcs[e] = cell_start[G0.cell_base + ((long long)(bz0 + rz) * G0.ny + (by0 + ry)) * G0.nx + bx0 + k];
-                    }
-                    __syncthreads();
-                    if (wave == 0) {
-                        // per-row point counts -> LDS offsets (exclusive scan over <= 96 rows)
-                        unsigned run = 0;
-                        for (int r0 = 0; r0 < NR; r0 += 64) {
-                            const int r = r0 + lane;
-                            unsigned g = 0, cnt = 0;
-                            if (r < NR) {
-                                g = lcs[r * (W + 1)];
-                                cnt = lcs[r * (W + 1) + W] - g;
-                            }
-                            unsigned inc = cnt;
-#pragma unroll
-                            for (int sft = 1; sft < 64; sft <<= 1) {
-                                unsigned t = __shfl_up(inc, sft);
-                                if (lane >= sft) inc += t;
-                            }
-                            if (r < NR) {
-                                rowg[r] = g;
-                                rowdelta[r] = g - (run + inc - cnt);
-                            }
-                            run += __shfl(inc, 63);
-                        }
-                        if (lane == 0) s_total = run;
-                    }
-                    __syncthreads();
-                    tiled = s_total <= (unsigned)T_MAXP;
-                    if (tiled) {
-                        for (int r = 0; r < NR; ++r) {
-                            const unsigned g = rowg[r], cnt = lcs[r * (W + 1) + W] - g, dl = rowdelta[r];
-                            for (unsigned k = threadIdx.x; k < cnt; k += BLOCK) lpts[g + k - dl] = sorted[g + k];
-                        }
-                        __syncthreads();
-                    }
-                }
-            }
+        bool need = ok;  // still needs the grid search
+        if (ok && wp != 0xffffffffu) {
+            const float4 wc = sorted[wp];
+            const float ws = safe_r2[wp];
+            B.consider(sqdist(px, py, pz, wc.x, wc.y, wc.z), wc, wp);
+            need = !(B.d < ws);  // inside the safe radius: proven nearest, no search
         }
-
-        if (ok) {
-            if (wp != 0xffffffffu) B.consider(sqdist(px, py, pz, wc.x, wc.y, wc.z), wc, wp);
-            int next_level = 0;
-            if (tiled) {
-                const float mg = G0.margin;
-                const float bxl = fmaxf(C.fx0 - mg, 0.f), bxr = fmaxf(C.fx1 - mg, 0.f);
-                const bool has_l = C.cx > 0, has_r = C.cx + 1 < G0.nx;
-#pragma unroll 1
-                for (int r = 0; r < 9; ++r) {
-                    const int kz = r / 3, ky = r - 3 * kz;
-                    const int dz = kz == 0 ? 0 : (kz == 1 ? -1 : 1);
-                    const int dy = ky == 0 ? 0 : (ky == 1 ? -1 : 1);
-                    const int zz = C.cz + dz, yy = C.cy + dy;
-                    if (zz < 0 || zz >= G0.nz || yy < 0 || yy >= G0.ny) continue;
-                    const float bz = dz == 0 ? 0.f : fmaxf((dz < 0 ? C.fz0 : C.fz1) - mg, 0.f);
-                    const float by = dy == 0 ? 0.f : fmaxf((dy < 0 ? C.fy0 : C.fy1) - mg, 0.f);
-                    const float rb2 = by * by + bz * bz;
-                    if (rb2 * 0.99999f > B.worst()) continue;
-                    const int lr = (zz - bz0) * NYb + (yy - by0);
-                    const int e = lr * (W + 1) + (C.cx - bx0);
-                    const unsigned c1 = lcs[e], c2 = lcs[e + 1];
-                    const unsigned c0 = has_l ? lcs[e - 1] : c1, c3 = has_r ? lcs[e + 2] : c2;
-                    const unsigned dl = rowdelta[lr];
-                    scan_run_lds(B, lpts, c1, c2, dl, px, py, pz);
-                    if (c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst()) scan_run_lds(B, lpts, c0, c1, dl, px, py, pz);
-                    if (c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst()) scan_run_lds(B, lpts, c2, c3, dl, px, py, pz);
-                }
-                next_level = B.worst() <= C.settled_r2(G0) ? P.nlevels : 1;
-            }
-            if (next_level < P.nlevels && !(diag & 1)) knn_query(P, sorted, cell_start, px, py, pz, B, next_level);
-        }
+        if (diag & 1) need = false;
+        knn_query(P, sorted, cell_start, need, px, py, pz, B);
+        if (!valid) continue;
         ok = ok && B.i != 0x7fffffff;
-        if (valid) {
-            nn_idx[P.src_off + i] = ok ? B.i : -1;
-            nn_sqd[P.src_off + i] = ok ? B.d : INFINITY;
-            nn_pos[P.src_off + i] = ok ? B.pos : 0xffffffffu;
+        nn_idx[P.src_off + i] = ok ? B.i : -1;
+        nn_sqd[P.src_off + i] = ok ? B.d : INFINITY;
+        nn_pos[P.src_off + i] = ok ? B.pos : 0xffffffffu;
+        if (!ok) continue;
+        const double dpx = px, dpy = py, dpz = pz, qx = B.x, qy = B.y, qz = B.z;
+        if (WEIGHTED) {
+            const double w = wsrc[P.src_off + i], w2 = w * w;
+            acc[0] += w;
+            acc[1] += w * dpx; acc[2] += w * dpy; acc[3] += w * dpz;
+            acc[4] += w * qx;  acc[5] += w * qy;  acc[6] += w * qz;
+            const double ax = w2 * dpx, ay = w2 * dpy, az = w2 * dpz;
+            acc[7] += ax * qx;  acc[8] += ax * qy;  acc[9] += ax * qz;
+            acc[10] += ay * qx; acc[11] += ay * qy; acc[12] += ay * qz;
+            acc[13] += az * qx; acc[14] += az * qy; acc[15] += az * qz;
+            acc[16] += sqrt((double)B.d);
+            acc[17] += w2;
+            acc[18] += ax; acc[19] += ay; acc[20] += az;
+            acc[21] += w2 * qx; acc[22] += w2 * qy; acc[23] += w2 * qz;
+            acc[24] += 1.0;
+        } else {
+            acc[0] += 1.0;
+            acc[1] += dpx; acc[2] += dpy; acc[3] += dpz;
+            acc[4] += qx;  acc[5] += qy;  acc[6] += qz;
+            acc[7] += dpx * qx;  acc[8] += dpx * qy;  acc[9] += dpx * qz;
+            acc[10] += dpy * qx; acc[11] += dpy * qy; acc[12] += dpy * qz;
+            acc[13] += dpz * qx; acc[14] += dpz * qy; acc[15] += dpz * qz;
+            acc[16] += sqrt((double)B.d);
         }
-        if (ok) {
-            const double dpx = px, dpy = py, dpz = pz, qx = B.x, qy = B.y, qz = B.z;
-            if (WEIGHTED) {
-                const double w = wsrc[P.src_off + i], w2 = w * w;
-                acc[0] += w;
-                acc[1] += w * dpx; acc[2] += w * dpy; acc[3] += w * dpz;
-                acc[4] += w * qx;  acc[5] += w * qy;  acc[6] += w * qz;
-                const double ax = w2 * dpx, ay = w2 * dpy, az = w2 * dpz;
-                acc[7] += ax * qx;  acc[8] += ax * qy;  acc[9] += ax * qz;
-                acc[10] += ay * qx; acc[11] += ay * qy; acc[12] += ay * qz;
-                acc[13] += az * qx; acc[14] += az * qy; acc[15] += az * qz;
-                acc[16] += sqrt((double)B.d);
-                acc[17] += w2;
-                acc[18] += ax; acc[19] += ay; acc[20] += az;
-                acc[21] += w2 * qx; acc[22] += w2 * qy; acc[23] += w2 * qz;
-                acc[24] += 1.0;
-            } else {
-                acc[0] += 1.0;
-                acc[1] += dpx; acc[2] += dpy; acc[3] += dpz;
-                acc[4] += qx;  acc[5] += qy;  acc[6] += qz;
-                acc[7] += dpx * qx;  acc[8] += dpx * qy;  acc[9] += dpx * qz;
-                acc[10] += dpy * qx; acc[11] += dpy * qy; acc[12] += dpy * qz;
-                acc[13] += dpz * qx; acc[14] += dpz * qy; acc[15] += dpz * qz;
-                acc[16] += sqrt((double)B.d);
-            }
-        }
-        if (QPT > 1) __syncthreads();  // the tile is re-staged by the next batch
     }
-    // wave shuffle reduction, then the 4 wave totals through LDS (fixed order)
+    // DPP wave reduction, then the 4 wave totals through LDS (fixed order)
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
         double v = (diag & 2) ? acc[k] : wave_sum(acc[k]);
@@ -801,6 +776,7 @@ struct GridSet {
     DevBuf<PairDesc> pairs;
     DevBuf<float4> pts4;    // caller order
     DevBuf<float4> sorted;  // all (pair, level) blocks
+    DevBuf<float> safe_r2;  // per sorted position: certified-nearest radius^2 (lazy, ICP only)
     DevBuf<unsigned> cell_start_buf;  // 4 pad + cells + 1 + 4 pad
     unsigned *cell_start = nullptr;
     long long total_cells = 0, total_sorted = 0;
@@ -954,6 +930,31 @@ static int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long 
     return GPSCAL_OK;
 }
 
+// Certified-nearest radii for every sorted position (ICP only; built on first use).
+static int ensure_safe_radius(gpscal_ctx *ctx, GridSet &gs)
+{
+    if (gs.safe_r2.p || gs.total_sorted == 0) {
+        if (!gs.safe_r2.p) GPSCAL_HIP(ctx, gs.safe_r2.alloc(1));
+        return GPSCAL_OK;
+    }
+    const long long total = gs.off[gs.npairs] - gs.off[0];
+    DevBuf<float> d2nn;
+    GPSCAL_HIP(ctx, d2nn.alloc((size_t)std::max<long long>(total, 1)));
+    // non-finite points are never indexed: their slot reads as "no neighbour"
+    GPSCAL_HIP(ctx, hipMemsetAsync(d2nn.p, 0x7f, sizeof(float) * (size_t)std::max<long long>(total, 1), ctx->stream));
+    GPSCAL_HIP(ctx, gs.safe_r2.alloc((size_t)gs.total_sorted));
+    int mmax = 0;
+    for (auto &P : gs.hpairs) mmax = std::max(mmax, P.m);
+    int gx = std::max(1, std::min(div_up(mmax, BLOCK), 4096));
+    hipLaunchKernelGGL(self_nn_kernel, dim3(gx, gs.npairs), dim3(BLOCK), 0, ctx->stream, gs.pairs.p, gs.sorted.p,
+                       gs.cell_start, d2nn.p);
+    hipLaunchKernelGGL(safe_radius_kernel, dim3(div_up(gs.total_sorted, BLOCK)), dim3(BLOCK), 0, ctx->stream,
+                       gs.sorted.p, d2nn.p, gs.pairs.p, gs.npairs, gs.cell_start, gs.safe_r2.p, gs.total_sorted);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}
+
 }  // namespace gpscal
 
 using namespace gpscal;
@@ -970,7 +971,7 @@ struct gpscal_scan_batch {
     int npairs = 0;
     long long total_n = 0;
     bool weighted = false;
-    int qpt = 1, nblk = 0, use_tile = 1, diag = 0;
+    int qpt = 1, nblk = 0, diag = 0;
     DevBuf<PairDesc> pairs;  // target descs + source fields
     std::vector<PairDesc> hpairs;
     DevBuf<float4> src4;
@@ -1100,10 +1101,8 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
                                    hipMemcpyDeviceToDevice, ctx->stream));
     // block table
     const long long per_blk_target = (long long)ctx->prop.multiProcessorCount * 8 * BLOCK;
-    (void)per_blk_target;
-    B->qpt = 1;  // one batch per workgroup keeps the tiled kernel at 78 VGPRs
+    B->qpt = B->total_n >= 4 * per_blk_target ? 4 : 1;
     if (const char *e = getenv("GPSCAL_QPT")) B->qpt = atoi(e) == 4 ? 4 : 1;  // tuning knobs
-    if (const char *e = getenv("GPSCAL_TILE")) B->use_tile = atoi(e) != 0;
     if (const char *e = getenv("GPSCAL_DIAG")) B->diag = atoi(e);  // ablation (wrong results!)
     std::vector<int> bp, bf;
     for (int b = 0; b < np; ++b) {
@@ -1160,6 +1159,7 @@ extern "C" int gpscal_scan_batch_create(gpscal_ctx *ctx, int npairs, const float
     B->tgt = new GridSet;
     std::vector<long long> to(tgt_off, tgt_off + npairs + 1), so(src_off, src_off + npairs + 1);
     int rc = build_grids(ctx, tgt_xyz, 12, to.data(), npairs, cell, MAX_LEVELS, *B->tgt);
+    if (!rc) rc = ensure_safe_radius(ctx, *B->tgt);
     if (!rc) rc = batch_setup_sources(B, src_xyz, 12, so.data(), w);
     if (rc) {
         delete B;
@@ -1198,8 +1198,9 @@ static void launch_step(gpscal_scan_batch *B)
     if (B->nblk == 0) return;
 #define STEP(QPT, W)                                                                                         \
     hipLaunchKernelGGL((icp_step_kernel<QPT, W>), dim3(B->nblk), dim3(BLOCK), 0, ctx->stream, B->pairs.p,     \
-                       B->blk_pair.p, B->blk_first.p, B->src4.p, B->wsorted.p, G.sorted.p, G.cell_start,     \
-                       B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->nn_pos.p, B->partials.p, B->nblk, B->use_tile, B->diag)
+                       B->blk_pair.p, B->blk_first.p, B->src4.p, B->wsorted.p, G.sorted.p, G.safe_r2.p,       \
+                       G.cell_start, B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->nn_pos.p, B->partials.p,       \
+                       B->nblk, B->diag)
     if (B->weighted) {
         if (B->qpt == 4) STEP(4, true); else STEP(1, true);
     } else {
@@ -1332,7 +1333,8 @@ static int make_borrowed_batch(gpscal_ctx *ctx, gpscal_knn_index *index, const f
     B->tgt = &index->gs;
     B->borrowed = true;
     long long so[2] = {0, n};
-    int rc = batch_setup_sources(B, src, stride, so, w);
+    int rc = ensure_safe_radius(ctx, index->gs);
+    if (!rc) rc = batch_setup_sources(B, src, stride, so, w);
     if (rc) {
         delete B;
         return rc;

@@ -47,4 +47,27 @@ __device__ __forceinline__ int wave_min(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// min over the wave of a 64-bit unsigned key (arg-min of (distance, index) pairs)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long v)
+{
+    unsigned lo = (unsigned)dpp_mov<CTRL, ROW_MASK>((int)(unsigned)v, (int)(unsigned)v);
+    unsigned hi = (unsigned)dpp_mov<CTRL, ROW_MASK>((int)(unsigned)(v >> 32), (int)(unsigned)(v >> 32));
+    unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return o < v ? o : v;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+    v = dpp_min_u64<0x111, 0xF>(v);
+    v = dpp_min_u64<0x112, 0xF>(v);
+    v = dpp_min_u64<0x114, 0xF>(v);
+    v = dpp_min_u64<0x118, 0xF>(v);
+    v = dpp_min_u64<0x142, 0xA>(v);
+    v = dpp_min_u64<0x143, 0xC>(v);
+    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 }  // namespace gpscal
