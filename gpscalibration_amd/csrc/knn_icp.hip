@@ -31,7 +31,7 @@
 
 namespace gpscal {
 
-constexpr int MAX_LEVELS = 6;
+constexpr int MAX_LEVELS = 8;
 constexpr int BLOCK = 256;
 constexpr int NACC_PLAIN = 17;   // n, sum p(3), sum q(3), sum p q^T(9), sum dist
 constexpr int NACC_WEIGHTED = 25;  // + sw, sw2, sum w2 p(3), sum w2 q(3) (w-sums replace n)
@@ -292,32 +292,30 @@ struct Best {
     }
 };
 
-// 1-NN record of the ICP kernel: keeps the neighbour's coordinates (no second
-// gather) and its position in `sorted` (next iteration's warm start).
+// 1-NN record of the ICP kernel.  (d2, index) live in one 64-bit key -- d2 >= 0, so
+// its float bits order like the value and the key orders exactly like (d2, index):
+// accepting a candidate is one v_cmp_lt_u64 and three v_cndmask.  `pos` is the
+// winner's position in `sorted` (WARM = the warm-start candidate is still best).
 struct BestQ {
     static constexpr bool COOP = true;  // long runs are scanned by the whole wave
-    float d;
-    int i;
+    static constexpr unsigned WARM = 0xffffffffu;
+    static constexpr unsigned LIST = 0xfffffff0u;  // LIST + j: j-th entry of q0's neighbour list
+    unsigned long long key;
     unsigned pos;
-    float x, y, z;
     __device__ __forceinline__ void init()
     {
-        d = INFINITY;
-        i = 0x7fffffff;
-        pos = 0xffffffffu;
-        x = y = z = 0.f;
+        key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, INT_MAX)
+        pos = WARM;
     }
-    __device__ __forceinline__ float worst() const { return d; }
+    __device__ __forceinline__ float dist2() const { return __uint_as_float((unsigned)(key >> 32)); }
+    __device__ __forceinline__ int index() const { return (int)(unsigned)key; }
+    __device__ __forceinline__ float worst() const { return dist2(); }
     __device__ __forceinline__ void consider(float d2, const float4 &c, unsigned p)
     {
-        const int idx = __float_as_int(c.w);
-        if (d2 < d || (d2 == d && idx < i)) {
-            d = d2;
-            i = idx;
+        const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(c.w);
+        if (k2 < key) {
+            key = k2;
             pos = p;
-            x = c.x;
-            y = c.y;
-            z = c.z;
         }
     }
 };
@@ -347,7 +345,8 @@ __device__ __forceinline__ void scan_short(BT &B, bool act, const float4 *__rest
     }
 }
 
-constexpr unsigned COOP_MIN = 12;  // runs longer than this are scanned by the whole wave
+constexpr unsigned COOP_MIN = 12;   // runs longer than this are worth the whole wave ...
+constexpr int COOP_MAX_OWNERS = 6;  // ... but only while few lanes have one (owners * L/64 < L/4)
 
 __device__ __forceinline__ float readlane_f(float v, int l)
 {
@@ -365,9 +364,13 @@ __device__ __forceinline__ void scan_runs(BT &B, bool act, const float4 *__restr
     if constexpr (!BT::COOP) {
         scan_short(B, act, sorted, s, e, px, py, pz);
     } else {
-        const bool lng = act && (e - s) > COOP_MIN;
-        scan_short(B, act && !lng, sorted, s, e, px, py, pz);
+        bool lng = act && (e - s) > COOP_MIN;
         unsigned long long m = __ballot(lng);
+        if (__popcll(m) > COOP_MAX_OWNERS) {  // everybody has work: lanes scan in parallel
+            m = 0ull;
+            lng = false;
+        }
+        scan_short(B, act && !lng, sorted, s, e, px, py, pz);
         const int lane = threadIdx.x & 63;
         while (m) {  // wave-uniform
             const int owner = __builtin_ctzll(m);
@@ -444,30 +447,63 @@ struct CellGeo {
 template <class BT>
 __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__restrict__ sorted,
                                           const unsigned *__restrict__ cell_start, bool act, float px, float py,
-                                          float pz, BT &B, int first_level = 0)
+                                          float pz, BT &B)
 {
     if (!act) px = py = pz = 0.f;
-    for (int l = first_level; l < P.nlevels; ++l) {
-        if (__ballot(act) == 0ull) break;
+    // A lane that already holds a candidate skips the levels that cannot settle it:
+    // level l settles every query whose best is within h_l (the 3x3x3 block reaches
+    // at least one cell beyond the query's own), so the first such level is searched
+    // alone.  Without a candidate (first iteration) the search starts at level 0.
+    int start = 0;
+    {
+        const float w0 = B.worst();
+        if (w0 < INFINITY) {
+            start = P.nlevels - 1;
+            for (int l = P.nlevels - 2; l >= 0; --l) {
+                const float g = P.lv[l].h * 0.999f - P.lv[l].margin;
+                if (g > 0.f && w0 <= g * g) start = l;
+            }
+        }
+    }
+    bool todo = act;
+    for (int l = 0; l < P.nlevels; ++l) {
+        if (__ballot(todo) == 0ull) break;
+        const bool act = todo && l >= start;
+        if (__ballot(act) == 0ull) continue;
         const GridDesc &G = P.lv[l];
         CellGeo C;
         C.set(G, px, py, pz);
         const float mg = G.margin;
         const float bxl = fmaxf(C.fx0 - mg, 0.f), bxr = fmaxf(C.fx1 - mg, 0.f);
         const bool has_l = C.cx > 0, has_r = C.cx + 1 < G.nx;
-#pragma unroll 1
-        for (int r = 0; r < 9; ++r) {
+        // face distances of the 3 x 3 rows: index 0 = own, 1 = lower, 2 = upper neighbour
+        const float by2[3] = {0.f, fmaxf(C.fy0 - mg, 0.f) * fmaxf(C.fy0 - mg, 0.f),
+                              fmaxf(C.fy1 - mg, 0.f) * fmaxf(C.fy1 - mg, 0.f)};
+        const float bz2[3] = {0.f, fmaxf(C.fz0 - mg, 0.f) * fmaxf(C.fz0 - mg, 0.f),
+                              fmaxf(C.fz1 - mg, 0.f) * fmaxf(C.fz1 - mg, 0.f)};
+        const bool yok[3] = {true, C.cy > 0, C.cy + 1 < G.ny};
+        const bool zok[3] = {true, C.cz > 0, C.cz + 1 < G.nz};
+        // rows some lane of the wave still has to look at (bit r = 3*kz + ky)
+        unsigned wavemask = 0;
+        {
+            const float w0 = B.worst();
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const bool p = act && yok[r % 3] && zok[r / 3] && (by2[r % 3] + bz2[r / 3]) * 0.99999f <= w0;
+                if (__ballot(p) != 0ull) wavemask |= 1u << r;
+            }
+        }
+        while (wavemask) {  // wave-uniform
+            const int r = __builtin_ctz(wavemask);
+            wavemask &= wavemask - 1;
             const int kz = r / 3, ky = r - 3 * kz;
-            const int dz = kz == 0 ? 0 : (kz == 1 ? -1 : 1);
-            const int dy = ky == 0 ? 0 : (ky == 1 ? -1 : 1);
-            const int zz = C.cz + dz, yy = C.cy + dy;
-            const float bz = dz == 0 ? 0.f : fmaxf((dz < 0 ? C.fz0 : C.fz1) - mg, 0.f);
-            const float by = dy == 0 ? 0.f : fmaxf((dy < 0 ? C.fy0 : C.fy1) - mg, 0.f);
-            const float rb2 = by * by + bz * bz;
-            const bool pass = act && zz >= 0 && zz < G.nz && yy >= 0 && yy < G.ny && rb2 * 0.99999f <= B.worst();
-            if (__ballot(pass) == 0ull) continue;  // no lane of the wave needs this row
+            const float rb2 = (ky == 0 ? 0.f : (ky == 1 ? by2[1] : by2[2])) + (kz == 0 ? 0.f : (kz == 1 ? bz2[1] : bz2[2]));
+            const bool inr = (ky == 0 || (ky == 1 ? yok[1] : yok[2])) && (kz == 0 || (kz == 1 ? zok[1] : zok[2]));
+            const bool pass = act && inr && rb2 * 0.99999f <= B.worst();
+            if (__ballot(pass) == 0ull) continue;  // an earlier row tightened the bound
             unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
             if (pass) {
+                const int zz = C.cz + (kz == 0 ? 0 : (kz == 1 ? -1 : 1)), yy = C.cy + (ky == 0 ? 0 : (ky == 1 ? -1 : 1));
                 const long long row = G.cell_base + ((long long)zz * G.ny + yy) * G.nx + C.cx;
                 // cell_start[row-1 .. row+2]: left | own | right cell boundaries
                 const CellQuad q = *reinterpret_cast<const CellQuad *>(cell_start + row - 1);
@@ -479,7 +515,7 @@ __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__res
             if (__ballot(pl) != 0ull) scan_runs(B, pl, sorted, c0, c1, px, py, pz);
             if (__ballot(pr) != 0ull) scan_runs(B, pr, sorted, c2, c3, px, py, pz);
         }
-        if (act && B.worst() <= C.settled_r2(G)) act = false;
+        if (act && B.worst() <= C.settled_r2(G)) todo = false;
     }
 }
 
@@ -510,12 +546,20 @@ __global__ __launch_bounds__(BLOCK) void knn_search_kernel(const PairDesc *__res
     }
 }
 
-// Self-neighbour pass of the index build: for every target point the squared
-// distance to its nearest OTHER point (second of a k=2 search at its own position).
+// Self-neighbour pass of the index build (ICP only).  For every target point q0, by
+// ORIGINAL index g = tgt_off + idx:
+//   nbr[g][0..3]  its 4 nearest other points (xyz + index bits),
+//   pt_r2[g].x    r_a^2 = (D1/2)^2: a query closer than r_a to q0 has q0 as its unique
+//                 nearest neighbour (|p-q| >= D1 - |p-q0| > |p-q0| for every other q);
+//   pt_r2[g].y    r_b^2 = (D5/2)^2: closer than r_b, the nearest neighbour is q0 or one of
+//                 the 4 listed points (everything else is at least D5 from q0).
+// D1 / D5 = distance from q0 to its nearest / 5th nearest other point.  The 0.99 factor
+// absorbs the float rounding of the three distances involved.
 __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restrict__ pairs,
                                                          const float4 *__restrict__ sorted,
                                                          const unsigned *__restrict__ cell_start,
-                                                         float *__restrict__ d2nn)
+                                                         const float4 *__restrict__ pts4, float4 *__restrict__ nbr,
+                                                         float2 *__restrict__ pt_r2)
 {
     const int b = blockIdx.y;
     const PairDesc &P = pairs[b];
@@ -527,44 +571,59 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
         const bool act = j < end0;
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
         if (act) c = sorted[j];
-        Best<2> B;
+        Best<6> B;
         B.init();
         knn_query(P, sorted, cell_start, act, c.x, c.y, c.z, B);
-        if (act) d2nn[P.tgt_off + __float_as_int(c.w)] = B.d[1];  // +inf for a single-point cloud
+        if (!act) continue;
+        const int own = __float_as_int(c.w);
+        const long long g = P.tgt_off + own;
+        // the five nearest OTHER points, in (d2, index) order
+        float od[5];
+        int oi[5];
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (B.i[k] != own && n < 5) {
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+                    if (t == n) {
+                        od[t] = B.d[k];
+                        oi[t] = B.i[k];
+                    }
+                ++n;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+            if (t >= n) {
+                od[t] = INFINITY;
+                oi[t] = 0x7fffffff;
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // a missing entry (cloud of < 5 points) sits at infinity: never the nearest
+            float4 v = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
+            if (oi[t] != 0x7fffffff) v = pts4[P.tgt_off + oi[t]];
+            nbr[4 * g + t] = v;
+        }
+        pt_r2[g] = make_float2(isfinite(od[0]) ? 0.25f * 0.99f * od[0] : 3.0e38f,
+                               isfinite(od[4]) ? 0.25f * 0.99f * od[4] : 3.0e38f);
     }
-}
-
-// safe_r2[pos]: if a query is closer than this (squared) to sorted[pos], that point
-// is certainly its unique nearest neighbour: with r = half the distance from the
-// point to its own nearest neighbour, |p-q| < r implies |p-q'| >= 2r - |p-q| > |p-q|
-// for every other q'.  The 0.99 factor absorbs float rounding of all three distances.
-__global__ void safe_radius_kernel(const float4 *__restrict__ sorted, const float *__restrict__ d2nn,
-                                   const PairDesc *__restrict__ pairs, int npairs,
-                                   const unsigned *__restrict__ cell_start, float *__restrict__ safe_r2,
-                                   long long total_sorted)
-{
-    long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= total_sorted) return;
-    // pair owning this position: last b whose first level-0 position is <= pos
-    int lo = 0, hi = npairs;
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if ((long long)cell_start[pairs[mid].lv[0].cell_base] <= pos) lo = mid; else hi = mid;
-    }
-    const float d2 = d2nn[pairs[lo].tgt_off + __float_as_int(sorted[pos].w)];
-    safe_r2[pos] = isfinite(d2) ? 0.25f * 0.99f * d2 : 3.0e38f;
 }
 
 // The fused ICP correspondence kernel: transform -> exact 1-NN -> weighted
 // centroid / covariance partials.  One lane per source point, QPT batches of 256
 // consecutive points of the spatially grouped source per workgroup.
 //
-// Per query, cheapest test first:
-//   1. warm start: last iteration's neighbour (one 16-byte gather + its safe radius);
-//      inside the safe radius it is PROVEN to be the nearest neighbour: no search;
-//   2. otherwise the multi-level grid search, seeded with that candidate so the row
-//      and cell bounds prune most of the 3x3x3 block; long runs of candidates are
-//      scanned by the whole wave (scan_runs).
+// Per query, cheapest test first (all exact, see self_nn_kernel for the proofs):
+//   1. warm start: last iteration's neighbour q0 and its two radii are read back from
+//      per-query streams; closer than r_a, q0 is PROVEN to be the nearest neighbour;
+//   2. closer than r_b, the answer is q0 or one of its 4 listed neighbours: one 64-byte
+//      gather, five distance evaluations;
+//   3. otherwise the multi-level grid search, seeded with the best so far so the row and
+//      cell bounds prune most of the 3x3x3 block; long runs of candidates are scanned
+//      by the whole wave (scan_runs).
+// In a converged alignment ~93 % of the queries stop at 1 and nearly all others at 2.
 // An LDS-staged variant of level 0 (workgroup box of cells copied to LDS) was built
 // and measured SLOWER than this pruned global path (the box holds ~3.3 points per
 // query against ~2.4 the query reads); see DESIGN.md.
@@ -572,12 +631,13 @@ template <int QPT, bool WEIGHTED>
 __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
     const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
     const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
-    const float *__restrict__ safe_r2, const unsigned *__restrict__ cell_start, const float *__restrict__ pose32,
-    int *__restrict__ nn_idx, float *__restrict__ nn_sqd, unsigned *__restrict__ nn_pos,
-    double *__restrict__ partials, int nblk, int diag)
+    const float4 *__restrict__ nbr, const float2 *__restrict__ pt_r2, const unsigned *__restrict__ cell_start,
+    const float *__restrict__ pose32, int *__restrict__ nn_idx, float *__restrict__ nn_sqd,
+    float4 *__restrict__ warm_q, float2 *__restrict__ warm_r2, double *__restrict__ partials, int nblk, int diag)
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
     __shared__ double wsum[BLOCK / 64][NACC];
+    __shared__ double tslab[BLOCK / 64][8][64];  // per-wave transpose slab (16 KiB / block)
 
     const int lb = xcd_remap(blockIdx.x, nblk);
     const int b = __builtin_amdgcn_readfirstlane(blk_pair[lb]);
@@ -598,10 +658,13 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
         const int i = first + q * BLOCK + (int)threadIdx.x;
         const bool valid = i < P.n;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        unsigned wp = 0xffffffffu;
+        float4 wq = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
+        float2 wr2 = make_float2(0.f, 0.f);
         if (valid) {
+            // three coalesced streams: the point, last iteration's neighbour, its radii
             s = src4[P.src_off + i];
-            wp = nn_pos[P.src_off + i];
+            wq = warm_q[P.src_off + i];
+            wr2 = warm_r2[P.src_off + i];
         }
         bool ok = valid && finite3(s.x, s.y, s.z);
         const float px = __fmaf_rn(r00, s.x, __fmaf_rn(r01, s.y, __fmaf_rn(r02, s.z, tx)));
@@ -610,21 +673,38 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
         BestQ B;
         B.init();
         bool need = ok;  // still needs the grid search
-        if (ok && wp != 0xffffffffu) {
-            const float4 wc = sorted[wp];
-            const float ws = safe_r2[wp];
-            B.consider(sqdist(px, py, pz, wc.x, wc.y, wc.z), wc, wp);
-            need = !(B.d < ws);  // inside the safe radius: proven nearest, no search
+        float4 nq = wq;  // the neighbour this iteration ends with
+        if (ok && __float_as_int(wq.w) != 0x7fffffff) {
+            const float d0 = sqdist(px, py, pz, wq.x, wq.y, wq.z);
+            B.consider(d0, wq, BestQ::WARM);
+            need = !(d0 < wr2.x);  // tier 1: inside r_a, proven nearest
+            if (need && d0 < wr2.y && !(diag & 4)) {
+                // tier 2: inside r_b the answer is q0 or one of its 4 listed neighbours
+                const float4 *nb = nbr + 4 * (P.tgt_off + __float_as_int(wq.w));
+                const float4 n0 = nb[0], n1 = nb[1], n2 = nb[2], n3 = nb[3];
+                B.consider(sqdist(px, py, pz, n0.x, n0.y, n0.z), n0, BestQ::LIST + 0);
+                B.consider(sqdist(px, py, pz, n1.x, n1.y, n1.z), n1, BestQ::LIST + 1);
+                B.consider(sqdist(px, py, pz, n2.x, n2.y, n2.z), n2, BestQ::LIST + 2);
+                B.consider(sqdist(px, py, pz, n3.x, n3.y, n3.z), n3, BestQ::LIST + 3);
+                need = false;
+            }
         }
         if (diag & 1) need = false;
         knn_query(P, sorted, cell_start, need, px, py, pz, B);
         if (!valid) continue;
-        ok = ok && B.i != 0x7fffffff;
-        nn_idx[P.src_off + i] = ok ? B.i : -1;
-        nn_sqd[P.src_off + i] = ok ? B.d : INFINITY;
-        nn_pos[P.src_off + i] = ok ? B.pos : 0xffffffffu;
+        ok = ok && B.index() != 0x7fffffff;
+        if (ok && B.pos != BestQ::WARM) {
+            // the neighbour changed: remember it and its radii for the next iteration
+            nq = B.pos < BestQ::LIST ? sorted[B.pos]
+                                     : nbr[4 * (P.tgt_off + __float_as_int(wq.w)) + (B.pos - BestQ::LIST)];
+            warm_q[P.src_off + i] = nq;
+            warm_r2[P.src_off + i] = pt_r2[P.tgt_off + B.index()];
+        }
+        const float bd = B.dist2();
+        nn_idx[P.src_off + i] = ok ? B.index() : -1;
+        nn_sqd[P.src_off + i] = ok ? bd : INFINITY;
         if (!ok) continue;
-        const double dpx = px, dpy = py, dpz = pz, qx = B.x, qy = B.y, qz = B.z;
+        const double dpx = px, dpy = py, dpz = pz, qx = nq.x, qy = nq.y, qz = nq.z;
         if (WEIGHTED) {
             const double w = wsrc[P.src_off + i], w2 = w * w;
             acc[0] += w;
@@ -634,7 +714,7 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
             acc[7] += ax * qx;  acc[8] += ax * qy;  acc[9] += ax * qz;
             acc[10] += ay * qx; acc[11] += ay * qy; acc[12] += ay * qz;
             acc[13] += az * qx; acc[14] += az * qy; acc[15] += az * qz;
-            acc[16] += sqrt((double)B.d);
+            acc[16] += sqrt((double)bd);
             acc[17] += w2;
             acc[18] += ax; acc[19] += ay; acc[20] += az;
             acc[21] += w2 * qx; acc[22] += w2 * qy; acc[23] += w2 * qz;
@@ -646,14 +726,35 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
             acc[7] += dpx * qx;  acc[8] += dpx * qy;  acc[9] += dpx * qz;
             acc[10] += dpy * qx; acc[11] += dpy * qy; acc[12] += dpy * qz;
             acc[13] += dpz * qx; acc[14] += dpz * qy; acc[15] += dpz * qz;
-            acc[16] += sqrt((double)B.d);
+            acc[16] += sqrt((double)bd);
         }
     }
-    // DPP wave reduction, then the 4 wave totals through LDS (fixed order)
+    // Block reduction in fixed order.  Each wave transposes 8 accumulators at a time
+    // through its private LDS slab: lane (k, seg) sums 8 consecutive lanes' copies of
+    // value k (4 x ds_read_b128), three DPP steps fold the 8 segments.  ~80 VALU per
+    // wave against ~340 for 17 full DPP wave reductions (this kernel is VALU-bound).
+    if (diag & 2) {
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) {
-        double v = (diag & 2) ? acc[k] : wave_sum(acc[k]);
-        if (lane == 0) wsum[wave][k] = v;
+        for (int k = 0; k < NACC; ++k)
+            if (lane == 0) wsum[wave][k] = acc[k];
+    } else {
+        double *slab = &tslab[wave][0][0];
+#pragma unroll
+        for (int g0 = 0; g0 < NACC; g0 += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (g0 + k < NACC) slab[k * 64 + lane] = acc[g0 + k];
+            __builtin_amdgcn_wave_barrier();
+            const int k = lane >> 3, seg = lane & 7;
+            const double2 *row = reinterpret_cast<const double2 *>(slab + k * 64 + seg * 8);
+            const double2 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+            double v = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
+            v = dpp_add_f64<0x111, 0xF>(v);  // row_shr:1
+            v = dpp_add_f64<0x112, 0xF>(v);  // row_shr:2
+            v = dpp_add_f64<0x114, 0xF>(v);  // row_shr:4 -> lane 8k+7 holds value k
+            if (seg == 7 && g0 + k < NACC) wsum[wave][g0 + k] = v;
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     __syncthreads();
     if (threadIdx.x < NACC) {
@@ -734,6 +835,14 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const PairDesc *__restric
     }
 }
 
+__global__ void fill_warm_kernel(float4 *__restrict__ warm_q, float2 *__restrict__ warm_r2, long long n)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    warm_q[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));  // index INT_MAX = no warm start
+    warm_r2[i] = make_float2(0.f, 0.f);
+}
+
 __global__ void pose_to_f32_kernel(const double *__restrict__ pose64, float *__restrict__ pose32, int npairs)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -776,7 +885,8 @@ struct GridSet {
     DevBuf<PairDesc> pairs;
     DevBuf<float4> pts4;    // caller order
     DevBuf<float4> sorted;  // all (pair, level) blocks
-    DevBuf<float> safe_r2;  // per sorted position: certified-nearest radius^2 (lazy, ICP only)
+    DevBuf<float4> nbr;     // per original point: its 4 nearest other points (lazy, ICP only)
+    DevBuf<float2> pt_r2;   // per original point: (r_a^2, r_b^2) certified radii
     DevBuf<unsigned> cell_start_buf;  // 4 pad + cells + 1 + 4 pad
     unsigned *cell_start = nullptr;
     long long total_cells = 0, total_sorted = 0;
@@ -814,7 +924,9 @@ static void plan_levels(const float mn[3], const float mx[3], int m, float cell,
     int L = 1;
     float ratio = 4.0f;
     if (htop > h0 && max_levels > 1) {
-        L = 1 + (int)std::ceil(std::log(htop / h0) / std::log(4.0));
+        double step = 2.5;  // nominal cell-size ratio between levels (measured: 2.5 best of 2 / 2.5 / 4)
+        if (const char *e = getenv("GPSCAL_LEVEL_RATIO")) step = std::max(1.5, atof(e));
+        L = 1 + (int)std::ceil(std::log(htop / h0) / std::log(step));
         if (L > max_levels) L = max_levels;
         if (L < 2) L = 2;
         ratio = std::pow(htop / h0, 1.0f / (float)(L - 1));
@@ -930,26 +1042,23 @@ static int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long 
     return GPSCAL_OK;
 }
 
-// Certified-nearest radii for every sorted position (ICP only; built on first use).
+// Neighbour lists and certified radii of every target point (ICP only; first use).
 static int ensure_safe_radius(gpscal_ctx *ctx, GridSet &gs)
 {
-    if (gs.safe_r2.p || gs.total_sorted == 0) {
-        if (!gs.safe_r2.p) GPSCAL_HIP(ctx, gs.safe_r2.alloc(1));
-        return GPSCAL_OK;
-    }
+    if (gs.pt_r2.p) return GPSCAL_OK;
     const long long total = gs.off[gs.npairs] - gs.off[0];
-    DevBuf<float> d2nn;
-    GPSCAL_HIP(ctx, d2nn.alloc((size_t)std::max<long long>(total, 1)));
-    // non-finite points are never indexed: their slot reads as "no neighbour"
-    GPSCAL_HIP(ctx, hipMemsetAsync(d2nn.p, 0x7f, sizeof(float) * (size_t)std::max<long long>(total, 1), ctx->stream));
-    GPSCAL_HIP(ctx, gs.safe_r2.alloc((size_t)gs.total_sorted));
+    GPSCAL_HIP(ctx, gs.nbr.alloc((size_t)std::max<long long>(total, 1) * 4));
+    GPSCAL_HIP(ctx, gs.pt_r2.alloc((size_t)std::max<long long>(total, 1)));
+    // non-finite points are never indexed nor returned: their slots stay zero
+    GPSCAL_HIP(ctx, hipMemsetAsync(gs.nbr.p, 0, sizeof(float4) * 4 * (size_t)std::max<long long>(total, 1), ctx->stream));
+    GPSCAL_HIP(ctx, hipMemsetAsync(gs.pt_r2.p, 0, sizeof(float2) * (size_t)std::max<long long>(total, 1), ctx->stream));
     int mmax = 0;
     for (auto &P : gs.hpairs) mmax = std::max(mmax, P.m);
-    int gx = std::max(1, std::min(div_up(mmax, BLOCK), 4096));
-    hipLaunchKernelGGL(self_nn_kernel, dim3(gx, gs.npairs), dim3(BLOCK), 0, ctx->stream, gs.pairs.p, gs.sorted.p,
-                       gs.cell_start, d2nn.p);
-    hipLaunchKernelGGL(safe_radius_kernel, dim3(div_up(gs.total_sorted, BLOCK)), dim3(BLOCK), 0, ctx->stream,
-                       gs.sorted.p, d2nn.p, gs.pairs.p, gs.npairs, gs.cell_start, gs.safe_r2.p, gs.total_sorted);
+    if (mmax > 0) {
+        int gx = std::max(1, std::min(div_up(mmax, BLOCK), 4096));
+        hipLaunchKernelGGL(self_nn_kernel, dim3(gx, gs.npairs), dim3(BLOCK), 0, ctx->stream, gs.pairs.p, gs.sorted.p,
+                           gs.cell_start, gs.pts4.p, gs.nbr.p, gs.pt_r2.p);
+    }
     GPSCAL_HIP(ctx, hipGetLastError());
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GPSCAL_OK;
@@ -979,7 +1088,8 @@ struct gpscal_scan_batch {
     DevBuf<int> blk_pair, blk_first;
     DevBuf<int> nn_idx;
     DevBuf<float> nn_sqd;
-    DevBuf<unsigned> nn_pos;  // warm start: position of last iteration's neighbour in `sorted`
+    DevBuf<float4> warm_q;  // warm start: last iteration's neighbour (xyz + index bits) per source point
+    DevBuf<float2> warm_r2; // ... and its certified radii (r_a^2, r_b^2)
     DevBuf<double> partials, pose64, err_hist;
     DevBuf<float> pose32;
     int err_cap = 0;
@@ -1101,7 +1211,8 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
                                    hipMemcpyDeviceToDevice, ctx->stream));
     // block table
     const long long per_blk_target = (long long)ctx->prop.multiProcessorCount * 8 * BLOCK;
-    B->qpt = B->total_n >= 4 * per_blk_target ? 4 : 1;
+    (void)per_blk_target;
+    B->qpt = 1;  // measured: QPT 4 costs 117 VGPRs (4 waves/SIMD) and loses in the search-heavy early iterations
     if (const char *e = getenv("GPSCAL_QPT")) B->qpt = atoi(e) == 4 ? 4 : 1;  // tuning knobs
     if (const char *e = getenv("GPSCAL_DIAG")) B->diag = atoi(e);  // ablation (wrong results!)
     std::vector<int> bp, bf;
@@ -1136,8 +1247,10 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
     }
     GPSCAL_HIP(ctx, B->nn_idx.alloc((size_t)std::max<long long>(B->total_n, 1)));
     GPSCAL_HIP(ctx, B->nn_sqd.alloc((size_t)std::max<long long>(B->total_n, 1)));
-    GPSCAL_HIP(ctx, B->nn_pos.alloc((size_t)std::max<long long>(B->total_n, 1)));
-    GPSCAL_HIP(ctx, hipMemsetAsync(B->nn_pos.p, 0xff, sizeof(unsigned) * (size_t)std::max<long long>(B->total_n, 1), ctx->stream));
+    GPSCAL_HIP(ctx, B->warm_q.alloc((size_t)std::max<long long>(B->total_n, 1)));
+    GPSCAL_HIP(ctx, B->warm_r2.alloc((size_t)std::max<long long>(B->total_n, 1)));
+    hipLaunchKernelGGL(fill_warm_kernel, dim3(div_up(std::max<long long>(B->total_n, 1), BLOCK)), dim3(BLOCK), 0,
+                       ctx->stream, B->warm_q.p, B->warm_r2.p, B->total_n);
     GPSCAL_HIP(ctx, B->partials.alloc((size_t)std::max(B->nblk, 1) * NACC_WEIGHTED));
     GPSCAL_HIP(ctx, B->pose64.alloc((size_t)np * 16));
     GPSCAL_HIP(ctx, B->pose32.alloc((size_t)np * 12));
@@ -1198,9 +1311,9 @@ static void launch_step(gpscal_scan_batch *B)
     if (B->nblk == 0) return;
 #define STEP(QPT, W)                                                                                         \
     hipLaunchKernelGGL((icp_step_kernel<QPT, W>), dim3(B->nblk), dim3(BLOCK), 0, ctx->stream, B->pairs.p,     \
-                       B->blk_pair.p, B->blk_first.p, B->src4.p, B->wsorted.p, G.sorted.p, G.safe_r2.p,       \
-                       G.cell_start, B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->nn_pos.p, B->partials.p,       \
-                       B->nblk, B->diag)
+                       B->blk_pair.p, B->blk_first.p, B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p,  \
+                       G.cell_start, B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p,        \
+                       B->partials.p, B->nblk, B->diag)
     if (B->weighted) {
         if (B->qpt == 4) STEP(4, true); else STEP(1, true);
     } else {
