@@ -483,32 +483,42 @@ __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__res
                               fmaxf(C.fz1 - mg, 0.f) * fmaxf(C.fz1 - mg, 0.f)};
         const bool yok[3] = {true, C.cy > 0, C.cy + 1 < G.ny};
         const bool zok[3] = {true, C.cz > 0, C.cz + 1 < G.nz};
-        // rows some lane of the wave still has to look at (bit r = 3*kz + ky)
-        unsigned wavemask = 0;
+        // rows this lane (lanemask) / some lane of the wave (wavemask) still has to look
+        // at; bit r = 3*kz + ky
+        unsigned wavemask = 0, lanemask = 0;
         {
             const float w0 = B.worst();
 #pragma unroll
             for (int r = 0; r < 9; ++r) {
                 const bool p = act && yok[r % 3] && zok[r / 3] && (by2[r % 3] + bz2[r / 3]) * 0.99999f <= w0;
+                if (p) lanemask |= 1u << r;
                 if (__ballot(p) != 0ull) wavemask |= 1u << r;
             }
         }
+        // cell_start[row-1 .. row+2] of row r: left | own | right cell boundaries.  The
+        // next row's quad is fetched while the current row's candidates are scanned.
+        auto load_quad = [&](int r) -> CellQuad {
+            CellQuad q = {0u, 0u, 0u, 0u};
+            if ((lanemask >> r) & 1u) {
+                const int kz = r / 3, ky = r - 3 * kz;
+                const int zz = C.cz + (kz == 0 ? 0 : (kz == 1 ? -1 : 1)), yy = C.cy + (ky == 0 ? 0 : (ky == 1 ? -1 : 1));
+                const long long row = G.cell_base + ((long long)zz * G.ny + yy) * G.nx + C.cx;
+                q = *reinterpret_cast<const CellQuad *>(cell_start + row - 1);
+            }
+            return q;
+        };
+        CellQuad nxt = {0u, 0u, 0u, 0u};
+        if (wavemask) nxt = load_quad(__builtin_ctz(wavemask));
         while (wavemask) {  // wave-uniform
             const int r = __builtin_ctz(wavemask);
             wavemask &= wavemask - 1;
+            const CellQuad q = nxt;
+            if (wavemask) nxt = load_quad(__builtin_ctz(wavemask));
             const int kz = r / 3, ky = r - 3 * kz;
             const float rb2 = (ky == 0 ? 0.f : (ky == 1 ? by2[1] : by2[2])) + (kz == 0 ? 0.f : (kz == 1 ? bz2[1] : bz2[2]));
-            const bool inr = (ky == 0 || (ky == 1 ? yok[1] : yok[2])) && (kz == 0 || (kz == 1 ? zok[1] : zok[2]));
-            const bool pass = act && inr && rb2 * 0.99999f <= B.worst();
+            const bool pass = ((lanemask >> r) & 1u) && rb2 * 0.99999f <= B.worst();
             if (__ballot(pass) == 0ull) continue;  // an earlier row tightened the bound
-            unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            if (pass) {
-                const int zz = C.cz + (kz == 0 ? 0 : (kz == 1 ? -1 : 1)), yy = C.cy + (ky == 0 ? 0 : (ky == 1 ? -1 : 1));
-                const long long row = G.cell_base + ((long long)zz * G.ny + yy) * G.nx + C.cx;
-                // cell_start[row-1 .. row+2]: left | own | right cell boundaries
-                const CellQuad q = *reinterpret_cast<const CellQuad *>(cell_start + row - 1);
-                c0 = has_l ? q.a : q.b; c1 = q.b; c2 = q.c; c3 = has_r ? q.d : q.c;
-            }
+            const unsigned c0 = has_l ? q.a : q.b, c1 = q.b, c2 = q.c, c3 = has_r ? q.d : q.c;
             scan_runs(B, pass, sorted, c1, c2, px, py, pz);
             const bool pl = pass && c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst();
             const bool pr = pass && c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst();
