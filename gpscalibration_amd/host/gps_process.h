@@ -1,0 +1,44 @@
+// gps_process.h -- the part of the reference's GPSPro (include/gpsCalibration/
+// gps_process.h:24-57) that sits on the hot path: GPRMC ingest, GPSToENU, ENUToGPS,
+// colour segments, KML.  Text handling stays on the host; projection, interpolation and
+// the inverse projection run on the GPU (gpscal_gps_to_enu / gpscal_enu_to_wgs).
+// GCJ-02 / BD-09 / JSON outputs are out of scope this round.
+#ifndef GPSCAL_HOST_GPS_PROCESS_H
+#define GPSCAL_HOST_GPS_PROCESS_H
+#include "common.h"
+
+class GPSPro {
+public:
+    GPSPro();
+    int getType();
+    void setType(int type);
+    std::string getMethod();
+    void setMethod(std::string method);
+    std::string getGPSPath();
+    void setGPSPath(std::string originalGPSPath);
+    void setKMLConfigPath(std::string path);  // default: src/gpsCalibration/config/kml_config.xml (gps_process.cc:632)
+
+    // GPS coordinate -> ENU at the SLAM stamps (gps_process.cc:476-521).  Returns an empty
+    // vector (the reference exit(0)s) when the log has no fix for the track's time span.
+    std::vector<COORDXYZT> GPSToENU(std::vector<COORDXYZT> slamTrack);
+    // ENU -> WGS84 + 50 m colour segments (gps_process.cc:374-386, 600-626, 1010-1058)
+    int ENUToGPS(std::vector<COORDXYZTW> enuCoor, std::vector<std::pair<double, double> > &WGSBL,
+                 std::vector<double> &altitude, std::vector<std::pair<int, std::string> > &segmentColor);
+    // KML writer (gps_process.cc:759-847), flag 0 = original track, 1 = calibrated
+    int createKML(std::string KMLFileName, std::vector<std::pair<double, double> > WGSBL, std::vector<double> altitude,
+                  int flag, std::vector<std::pair<int, std::string> > segmentColor);
+
+    // host-side pieces, exposed for tests
+    static int parseGPRMC(const std::string &path, double startTime, double endTime, std::vector<double> &lat,
+                          std::vector<double> &lon, std::vector<double> &t);
+    static int gpsProcess(std::vector<double> &lat, std::vector<double> &lon, const std::vector<double> &t);
+    static std::vector<std::pair<int, std::string> > segment(const std::vector<COORDXYZTW> &enuCoor);
+
+private:
+    int type;
+    std::string method;
+    std::string originalGPSPath;
+    std::string kmlConfigPath;
+    std::vector<std::string> readKMLParameter();
+};
+#endif

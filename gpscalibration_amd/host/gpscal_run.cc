@@ -1,0 +1,191 @@
+// gpscal_run.cc -- ROS-free driver with run.sh's surface: the same parameters
+// (run.sh:27-61) as --name value options, the same two passes (long segments -> weights,
+// short overlapping segments -> fits -> overlap merge), the same outputs (original and
+// calibrated KML).  What roslaunch + the seven nodes do per message at 1 Hz
+// (input_data.cpp:251,333) happens here in two batched GPU launches.
+//
+// Input: rosbag reading and LOAM are not part of this round, so
+// the SLAM side enters as a track file, one block per segment exactly as input_data
+// publishes them on /slam_track (input_data.cpp:355-363):
+//     <track_flag> <n>          0 = long segment, 1 = short segment
+//     x y z t                   n lines, COORDXYZT
+// or as one continuous pose chain (--pose_chain) that is cut by travelled distance with
+// input_data's rule (long 1000 m / short 300 m with 100 m overlap, input_data.cpp:106-116).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <stdexcept>
+#include <string>
+
+#include "gps_process.h"
+#include "track_process.h"
+
+namespace {
+
+typedef std::vector<COORDXYZT> Track;
+
+bool read_tracks(const std::string &path, std::vector<Track> &longs, std::vector<Track> &shorts)
+{
+    std::ifstream in(path.c_str());
+    if (!in.is_open()) return false;
+    long flag, n;
+    while (in >> flag >> n) {
+        Track t(n);
+        for (long i = 0; i < n; ++i)
+            if (!(in >> t[i].x >> t[i].y >> t[i].z >> t[i].t)) return false;
+        (flag == 0 ? longs : shorts).push_back(t);
+    }
+    return true;
+}
+
+bool read_chain(const std::string &path, Track &chain)
+{
+    std::ifstream in(path.c_str());
+    if (!in.is_open()) return false;
+    COORDXYZT p;
+    while (in >> p.x >> p.y >> p.z >> p.t) chain.push_back(p);
+    return !chain.empty();
+}
+
+// input_data's segmentation by travelled 3-D distance: a segment ends once the path
+// exceeds `dist`; the next one restarts at the last pose within dist - overlap
+// (input_data.cpp:106-116,335-343); a tail shorter than dist/3 joins the previous segment
+// (input_data.cpp:367-424).  Every segment is re-based to its first pose, as LOAM restarts
+// from the origin per segment (laserOdometry.cpp:519-563).
+std::vector<Track> cut_segments(const Track &chain, double dist, double overlap)
+{
+    std::vector<std::pair<size_t, size_t> > spans;
+    size_t start = 0;
+    while (start + 1 < chain.size()) {
+        double acc = 0;
+        size_t resume = start, end = chain.size();
+        for (size_t i = start + 1; i < chain.size(); ++i) {
+            const double dx = chain[i].x - chain[i - 1].x, dy = chain[i].y - chain[i - 1].y, dz = chain[i].z - chain[i - 1].z;
+            acc += std::sqrt(dx * dx + dy * dy + dz * dz);
+            if (acc <= dist - overlap) resume = i;
+            if (acc > dist) {
+                end = i + 1;
+                break;
+            }
+        }
+        if (end == chain.size() && acc < dist / 3 && !spans.empty()) {
+            spans.back().second = chain.size();  // short tail: merged into the previous segment
+            break;
+        }
+        spans.push_back(std::make_pair(start, end));
+        if (end == chain.size()) break;
+        start = resume > start ? resume : end - 1;
+    }
+    std::vector<Track> out;
+    for (auto &sp : spans) {
+        Track t(chain.begin() + sp.first, chain.begin() + sp.second);
+        const COORDXYZT o = t[0];
+        for (auto &p : t) {
+            p.x -= o.x;
+            p.y -= o.y;
+            p.z = HEIGHT;  // transformMaintenance.cpp:149
+        }
+        out.push_back(t);
+    }
+    return out;
+}
+
+void usage()
+{
+    fprintf(stderr,
+            "usage: gpscal_run --gps_input_filename LOG (--slam_track_filename FILE | --pose_chain FILE)\n"
+            "       [--gps_original_filename out.kml] [--gps_improved_filename out.kml] [--result_control 1]\n"
+            "       [--total_long_distance 1000] [--total_short_distance 300] [--overlap_distance 100]\n"
+            "       [--ctm UTM|Gaussion] [--gdt 3|6] [--kml_config src/gpsCalibration/config/kml_config.xml]\n");
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    std::map<std::string, std::string> a;
+    a["result_control"] = "1";
+    a["gps_original_filename"] = "./data/original_gps_file.kml";   // run.sh:30-31
+    a["gps_improved_filename"] = "./data/calibration_gps_file.kml";
+    a["total_long_distance"] = "1000";                             // run.sh:46-48
+    a["total_short_distance"] = "300";
+    a["overlap_distance"] = "100";
+    a["ctm"] = "UTM";                                              // run.sh:60-61
+    a["gdt"] = "3";
+    for (int i = 1; i + 1 < argc; i += 2) {
+        if (strncmp(argv[i], "--", 2) != 0) {
+            usage();
+            return -1;
+        }
+        a[argv[i] + 2] = argv[i + 1];
+    }
+    if (!a.count("gps_input_filename") || (!a.count("slam_track_filename") && !a.count("pose_chain"))) {
+        usage();
+        return -1;
+    }
+    if (a["ctm"] != "UTM" && a["ctm"] != "Gaussion") {
+        fprintf(stderr, "ERROR: ctm=projectmethod(UTM/Gaussion)\n");  // long_distance_track_process.cpp:98-102
+        return -1;
+    }
+    const int gdt = atoi(a["gdt"].c_str());
+    if (gdt != 3 && gdt != 6) {
+        fprintf(stderr, "ERROR: gdt=bandwidth(3/6)\n");  // long_distance_track_process.cpp:104-108
+        return -1;
+    }
+    try {
+        std::vector<Track> longs, shorts;
+        if (a.count("slam_track_filename")) {
+            if (!read_tracks(a["slam_track_filename"], longs, shorts)) {
+                fprintf(stderr, "open %s error\n", a["slam_track_filename"].c_str());
+                return -1;
+            }
+        } else {
+            Track chain;
+            if (!read_chain(a["pose_chain"], chain)) {
+                fprintf(stderr, "open %s error\n", a["pose_chain"].c_str());
+                return -1;
+            }
+            longs = cut_segments(chain, atof(a["total_long_distance"].c_str()), 0.0);
+            shorts = cut_segments(chain, atof(a["total_short_distance"].c_str()), atof(a["overlap_distance"].c_str()));
+        }
+        GPSPro gps;
+        gps.setGPSPath(a["gps_input_filename"]);
+        gps.setMethod(a["ctm"]);
+        gps.setType(gdt);
+        if (a.count("kml_config")) gps.setKMLConfigPath(a["kml_config"]);
+
+        // pass 1: long segments -> whole-run ENU GPS + IRLS weights (the gps_weight topic)
+        LongDistanceTrackProcess lp(gps);
+        lp.processBatch(longs);
+        if (lp.totalTrack().empty()) {
+            fprintf(stderr, "WARN: no GPS track,please check it\n");  // long_distance_track_process.cpp:49
+            return -1;
+        }
+        // pass 2: short segments -> weighted fits -> overlap merge
+        ShortDistanceTrackProcess sp;
+        sp.setGPS(lp.totalTrack());
+        sp.processBatch(shorts);
+
+        std::vector<std::pair<double, double> > oriWGSBL, impWGSBL;
+        std::vector<double> oriAlt, impAlt;
+        std::vector<std::pair<int, std::string> > oriCol, impCol;
+        gps.ENUToGPS(sp.gps(), oriWGSBL, oriAlt, oriCol);        // short_distance_track_process.cpp:254-255
+        gps.ENUToGPS(sp.result(), impWGSBL, impAlt, impCol);
+        printf("oriWGSBL.size() = %zu\n", oriWGSBL.size());
+        const int rc = atoi(a["result_control"].c_str());
+        if (rc == 2 || rc == 3 || rc == 4)
+            fprintf(stderr, "result_control %d (Baidu/Gaode/ROS message) is not built yet: writing KML\n", rc);
+        printf("====================  Create original GPS KML  ====================\n");
+        gps.createKML(a["gps_original_filename"], oriWGSBL, oriAlt, 0, oriCol);
+        printf("==================== Create calibrated GPS KML ====================\n");
+        gps.createKML(a["gps_improved_filename"], impWGSBL, impAlt, 1, impCol);
+        printf("====================            END            ====================\n");
+    } catch (const std::exception &e) {
+        fprintf(stderr, "gpscal_run: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

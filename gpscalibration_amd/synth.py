@@ -174,3 +174,45 @@ def track_segments(nseg, poses, seed=7, rate_hz=10.0, gps_sigma=3.0, dropout=0.0
     slam[:, 3] = t
     return {"slam": slam, "seg_off": seg_off, "gprmc": text, "xy_true": xy, "t": t,
             "gps": (glat, glon, gt, valid)}
+
+
+def segmented_run(total_poses=3000, long_len=1000, short_len=300, overlap=100, seed=11, dropout=0.1):
+    """A whole synthetic run as input_data would publish it: long segments (flag 0) and
+    short overlapping segments (flag 1) cut from ONE drive, each re-based to its first pose
+    with its own unknown heading (LOAM restarts per segment).  Returns
+    (longs, shorts, gprmc_text) with segments as (n,4) arrays."""
+    d = track_segments(1, total_poses, seed=seed, dropout=dropout)
+    xy, t = d["xy_true"], d["t"]
+    rng = np.random.default_rng(seed + 1)
+
+    def make(a, b):
+        th = rng.uniform(0, 2 * math.pi)
+        c, s = math.cos(th), math.sin(th)
+        loc = xy[a:b] - xy[a] + np.cumsum(rng.normal(0, 0.002, size=(b - a, 2)), axis=0)
+        seg = np.empty((b - a, 4))
+        seg[:, 0] = c * loc[:, 0] - s * loc[:, 1]
+        seg[:, 1] = s * loc[:, 0] + c * loc[:, 1]
+        seg[:, 2] = 10.0
+        seg[:, 3] = t[a:b]
+        return seg
+
+    longs = [make(a, min(a + long_len, total_poses)) for a in range(0, total_poses, long_len)]
+    shorts = []
+    a = 0
+    while a < total_poses:
+        b = min(a + short_len, total_poses)
+        shorts.append(make(a, b))
+        if b == total_poses:
+            break
+        a = b - overlap
+    return longs, shorts, d["gprmc"]
+
+
+def write_track_file(path, longs, shorts):
+    """The driver's track-file format: '<flag> <n>' then n lines 'x y z t'."""
+    with open(path, "w") as f:
+        for flag, segs in ((0, longs), (1, shorts)):
+            for s in segs:
+                f.write("%d %d\n" % (flag, len(s)))
+                for r in s:
+                    f.write("%.17g %.17g %.17g %.17g\n" % tuple(r))

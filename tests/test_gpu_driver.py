@@ -1,0 +1,80 @@
+"""End-to-end: the ROS-free driver (host C++ mirror of the reference classes over the C ABI,
+GPU arithmetic) against the oracle chain on the same synthetic run -> KML coordinates and
+colours.  This is BASELINE configs[0]/[2]'s path with synthetic input (the demo bags are
+not in the container)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from gpscalibration_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUN = os.path.join(ROOT, "gpscalibration_amd", "host", "gpscal_run")
+
+
+def _kml_coords(text):
+    pts = []
+    for line in text.splitlines():
+        m = re.match(r"^(-?[\d.]+(?:e-?\d+)?),(-?[\d.]+(?:e-?\d+)?),(-?[\d.]+)$", line)
+        if m:
+            pts.append([float(m.group(1)), float(m.group(2)), float(m.group(3))])
+    return np.array(pts)
+
+
+def _oracle_run(longs, shorts, gprmc):
+    total = []
+    for s in longs:
+        lat, lon, t = O.parse_gprmc(gprmc, s[0, 3], s[-1, 3])
+        enu = O.gps_to_enu(lat, lon, t, s)
+        w, _ = O.long_segment(s[:len(enu)], enu, 5)
+        total.append(np.c_[enu, w])
+    gps = np.concatenate(total)
+    acc = None
+    for s in shorts:
+        so, go, wo = O.match_gps(gps, s)
+        _, _, cal, _ = O.track_fit(so, go, wo)
+        acc = O.merge_short(acc, cal, wo)
+    return gps, acc
+
+
+def test_driver_kml_matches_oracle(tmp_path):
+    if not os.path.exists(RUN):
+        pytest.fail("gpscal_run is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    longs, shorts, gprmc = synth.segmented_run(3000, 1000, 300, 100, seed=11, dropout=0.15)
+    trk, log = tmp_path / "tracks.txt", tmp_path / "gps.txt"
+    synth.write_track_file(str(trk), longs, shorts)
+    log.write_text(gprmc)
+    k0, k1 = tmp_path / "ori.kml", tmp_path / "cal.kml"
+    r = subprocess.run([RUN, "--gps_input_filename", str(log), "--slam_track_filename", str(trk),
+                        "--gps_original_filename", str(k0), "--gps_improved_filename", str(k1),
+                        "--kml_config", "/nonexistent"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    gps, acc = _oracle_run(longs, shorts, gprmc)
+    ll0, alt0 = O.local_to_wgs(gps)
+    ll1, alt1 = O.local_to_wgs(acc)
+    end1, rgb1 = O.colour_segments(acc)
+    ref0 = O.kml(ll0, alt0, 0)
+    ref1 = O.kml(ll1, alt1, 1, end1, rgb1)
+    got0, got1 = k0.read_text(), k1.read_text()
+    c0, c1 = _kml_coords(got0), _kml_coords(got1)
+    r0, r1 = _kml_coords(ref0), _kml_coords(ref1)
+    assert c0.shape == r0.shape == (len(gps), 3)
+    assert c1.shape == r1.shape == (len(acc) - 1, 3)  # last point never written (gps_process.cc:832)
+    assert np.abs(c0 - r0).max() < 1e-9   # degrees; north_star bar is 1e-6
+    assert np.abs(c1 - r1).max() < 1e-9
+    # same structure and per-segment colours (confidence colouring)
+    strip = lambda s: re.sub(r"^-?[\d.]+,-?[\d.]+,-?[\d.]+$", "C", s, flags=re.M)
+    assert strip(got0) == strip(ref0)
+    assert strip(got1) == strip(ref1)
+
+
+def test_driver_rejects_bad_arguments(tmp_path):
+    r = subprocess.run([RUN, "--gps_input_filename", "x", "--slam_track_filename", "y", "--ctm", "Mercator"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+    assert r.returncode != 0 and "UTM/Gaussion" in r.stdout
