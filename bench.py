@@ -42,7 +42,7 @@ def cpu_baseline(points, iters, budget_s=20.0):
     from gpscalibration_amd import synth
     done_iters, spent, pairs = 0, 0.0, 0
     build = 0.0
-    while spent < budget_s and pairs < 4:
+    while spent < budget_s and pairs < 64:
         tgt, src, _ = synth.scan_pair(points, pairs)
         t0 = time.perf_counter()
         kd = O.KdTree(tgt)
