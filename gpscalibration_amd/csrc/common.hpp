@@ -60,22 +60,42 @@ template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    hipStream_t pool_stream = nullptr;  // set: stream-ordered allocation (hipMallocAsync pool)
+    bool pooled = false;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (pooled) (void)hipFreeAsync(p, pool_stream);
+            else (void)hipFree(p);
+        }
         p = nullptr;
         n = 0;
     }
+    // Plain hipMalloc: for buffers that outlive the call (indices, batch state).
     hipError_t alloc(size_t count)
     {
         release();
         if (count == 0) count = 1;
+        pooled = false;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
         if (e == hipSuccess) n = count;
+        return e;
+    }
+    // Stream-ordered allocation from the device pool: for per-call temporaries.  Freed in
+    // stream order too, so no device-wide synchronisation (hipFree would add one).
+    hipError_t alloc_async(size_t count, hipStream_t stream)
+    {
+        release();
+        if (count == 0) count = 1;
+        pooled = true;
+        pool_stream = stream;
+        hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&p), count * sizeof(T), stream);
+        if (e == hipSuccess) n = count;
+        else pooled = false;
         return e;
     }
 };
@@ -95,7 +115,7 @@ struct InArg {
             dev = ptr;
             return hipSuccess;
         }
-        hipError_t e = tmp.alloc(count);
+        hipError_t e = tmp.alloc_async(count, ctx->stream);
         if (e != hipSuccess) return e;
         e = hipMemcpyAsync(tmp.p, ptr, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
         dev = tmp.p;
@@ -111,7 +131,7 @@ struct OutArg {
     T *host = nullptr;
     size_t count = 0;
     DevBuf<T> tmp;
-    hipError_t bind(gpscal_ctx *, T *ptr, size_t cnt)
+    hipError_t bind(gpscal_ctx *ctx, T *ptr, size_t cnt)
     {
         count = cnt;
         if (!ptr || cnt == 0) {
@@ -124,7 +144,7 @@ struct OutArg {
             return hipSuccess;
         }
         host = ptr;
-        hipError_t e = tmp.alloc(cnt);
+        hipError_t e = tmp.alloc_async(cnt, ctx->stream);
         dev = tmp.p;
         return e;
     }

@@ -51,7 +51,7 @@ struct PairDesc {
     int nlevels;
     int pblk_off;  // first partial slot of this pair
     int pblk_cnt;
-    int pad;
+    int coarse_from;  // first level whose cell counters are aggregated in LDS at build time
     GridDesc lv[MAX_LEVELS];
 };
 
@@ -163,21 +163,86 @@ __device__ __forceinline__ long long cell_of(const GridDesc &G, float x, float y
     return G.cell_base + ((long long)cz * G.ny + cy) * G.nx + cx;
 }
 
-// pass 0: count points per cell; pass 1: scatter into the sorted array.
-template <int PASS>
-__global__ void grid_fill_kernel(const PairDesc *__restrict__ pairs, const float4 *__restrict__ tgt4,
-                                 unsigned *__restrict__ counts, const unsigned *__restrict__ cell_start,
-                                 float4 *__restrict__ sorted)
+// Counting sort of every point into every level's cells, in two kernels.
+//
+// grid_count_kernel: rank of each point inside its cell = the value its atomicAdd on
+// the cell counter returns; the rank is kept so that the scatter pass needs no atomics.
+// Coarse levels have few cells (the top one <= 8): tens of thousands of global atomics on
+// a handful of addresses serialise, so their increments are aggregated per workgroup in
+// LDS (one LDS atomic per point, one global atomic per touched cell and workgroup).
+constexpr int CO_MAX = 4096;    // LDS histogram bins = cells of the aggregated levels
+constexpr int GC_PT = 4;        // points per thread
+constexpr int GC_CHUNK = BLOCK * GC_PT;
+
+__global__ __launch_bounds__(BLOCK) void grid_count_kernel(const PairDesc *__restrict__ pairs,
+                                                            const float4 *__restrict__ tgt4,
+                                                            unsigned *__restrict__ counts,
+                                                            unsigned *__restrict__ ranks, long long total_points)
 {
-    int b = blockIdx.y;
+    __shared__ unsigned hist[CO_MAX];
+    const int b = blockIdx.y;
+    const PairDesc &P = pairs[b];
+    const int base_i = blockIdx.x * GC_CHUNK;
+    if (base_i >= P.m) return;  // uniform
+    const int lc = P.coarse_from;  // levels lc.. are aggregated in LDS
+    const long long co_base = lc < P.nlevels ? P.lv[lc].cell_base : 0;
+    const GridDesc &Gt = P.lv[P.nlevels - 1];
+    const int nco = lc < P.nlevels ? (int)(Gt.cell_base + (long long)Gt.nx * Gt.ny * Gt.nz - co_base) : 0;
+    for (int t = threadIdx.x; t < nco; t += BLOCK) hist[t] = 0u;
+    __syncthreads();
+    unsigned rl[GC_PT][MAX_LEVELS];
+    float4 pt[GC_PT];
+#pragma unroll
+    for (int k = 0; k < GC_PT; ++k) {
+        const int i = base_i + k * BLOCK + (int)threadIdx.x;
+        pt[k] = make_float4(NAN, 0.f, 0.f, 0.f);
+        if (i < P.m) pt[k] = tgt4[P.tgt_off + i];
+        if (!finite3(pt[k].x, pt[k].y, pt[k].z)) continue;
+#pragma unroll
+        for (int l = 0; l < MAX_LEVELS; ++l) {
+            if (l >= P.nlevels) break;
+            const long long c = cell_of(P.lv[l], pt[k].x, pt[k].y, pt[k].z);
+            if (l < lc) {
+                ranks[(long long)l * total_points + P.tgt_off + i] = atomicAdd(&counts[c], 1u);
+            } else {
+                rl[k][l] = atomicAdd(&hist[(int)(c - co_base)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nco; t += BLOCK) {
+        const unsigned h = hist[t];
+        if (h) hist[t] = atomicAdd(&counts[co_base + t], h);  // base of this workgroup's points in the cell
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GC_PT; ++k) {
+        const int i = base_i + k * BLOCK + (int)threadIdx.x;
+        if (!finite3(pt[k].x, pt[k].y, pt[k].z)) continue;
+#pragma unroll
+        for (int l = 0; l < MAX_LEVELS; ++l) {
+            if (l >= P.nlevels) break;
+            if (l < lc) continue;
+            const long long c = cell_of(P.lv[l], pt[k].x, pt[k].y, pt[k].z);
+            ranks[(long long)l * total_points + P.tgt_off + i] = hist[(int)(c - co_base)] + rl[k][l];
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void grid_scatter_kernel(const PairDesc *__restrict__ pairs,
+                                                              const float4 *__restrict__ tgt4,
+                                                              const unsigned *__restrict__ ranks,
+                                                              const unsigned *__restrict__ cell_start,
+                                                              float4 *__restrict__ sorted, long long total_points)
+{
+    const int b = blockIdx.y;
     const PairDesc &P = pairs[b];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.m; i += gridDim.x * blockDim.x) {
-        float4 p = tgt4[P.tgt_off + i];
+        const float4 p = tgt4[P.tgt_off + i];
         if (!finite3(p.x, p.y, p.z)) continue;
         for (int l = 0; l < P.nlevels; ++l) {
-            long long c = cell_of(P.lv[l], p.x, p.y, p.z);
-            unsigned k = atomicAdd(&counts[c], 1u);
-            if (PASS == 1) sorted[cell_start[c] + k] = p;
+            const long long c = cell_of(P.lv[l], p.x, p.y, p.z);
+            sorted[cell_start[c] + ranks[(long long)l * total_points + P.tgt_off + i]] = p;
         }
     }
 }
@@ -238,16 +303,16 @@ static int exclusive_scan(gpscal_ctx *ctx, const unsigned *in, unsigned *out, lo
 {
     int tiles = div_up(n, SCAN_TILE);
     DevBuf<unsigned> sums, sums_scanned;
-    GPSCAL_HIP(ctx, sums.alloc(tiles));
+    GPSCAL_HIP(ctx, sums.alloc_async(tiles, ctx->stream));
     hipLaunchKernelGGL(scan_tile_kernel, dim3(tiles), dim3(BLOCK), 0, ctx->stream, in, out, sums.p, n);
     if (tiles > 1) {
-        GPSCAL_HIP(ctx, sums_scanned.alloc(tiles));
+        GPSCAL_HIP(ctx, sums_scanned.alloc_async(tiles, ctx->stream));
         int rc = exclusive_scan(ctx, sums.p, sums_scanned.p, tiles);
         if (rc) return rc;
         hipLaunchKernelGGL(scan_add_kernel, dim3(tiles), dim3(BLOCK), 0, ctx->stream, out, sums_scanned.p, n);
     }
     GPSCAL_HIP(ctx, hipGetLastError());
-    // temporaries are freed on return: hipFree synchronises the device first
+    // temporaries are returned to the pool in stream order
     return GPSCAL_OK;
 }
 
@@ -972,7 +1037,7 @@ static int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long 
     GPSCAL_HIP(ctx, raw.bind(ctx, static_cast<const char *>(xyz) + (size_t)off[0] * stride, (size_t)total * stride));
     GPSCAL_HIP(ctx, gs.pts4.alloc((size_t)total));
     DevBuf<long long> d_off;
-    GPSCAL_HIP(ctx, d_off.alloc(npairs + 1));
+    GPSCAL_HIP(ctx, d_off.alloc_async(npairs + 1, ctx->stream));
     std::vector<long long> rel(npairs + 1);
     for (int b = 0; b <= npairs; ++b) rel[b] = off[b] - off[0];
     GPSCAL_HIP(ctx, hipMemcpyAsync(d_off.p, rel.data(), sizeof(long long) * (npairs + 1), hipMemcpyHostToDevice,
@@ -988,7 +1053,7 @@ static int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long 
                            stride, d_off.p, npairs, total, gs.pts4.p);
     // bounding boxes
     DevBuf<int> d_bbox;
-    GPSCAL_HIP(ctx, d_bbox.alloc((size_t)npairs * 6));
+    GPSCAL_HIP(ctx, d_bbox.alloc_async((size_t)npairs * 6, ctx->stream));
     std::vector<int> hb((size_t)npairs * 6);
     for (int b = 0; b < npairs; ++b)
         for (int a = 0; a < 3; ++a) {
@@ -1015,6 +1080,17 @@ static int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long 
             if (!(mn[a] <= mx[a])) mn[a] = mx[a] = 0.f;  // empty / all-NaN cloud
         }
         plan_levels(mn, mx, P.m, cell, max_levels, P);
+        // levels whose cells (counted from the top) fit the LDS histogram are aggregated there
+        {
+            long long acc = 0;
+            P.coarse_from = P.nlevels;
+            for (int l = P.nlevels - 1; l >= 0; --l) {
+                const GridDesc &G = P.lv[l];
+                acc += G.tile ? (long long)G.nz * ((G.ny + 7) / 8) * ((G.nx + 7) / 8) * 64 : (long long)G.nx * G.ny * G.nz;
+                if (acc > CO_MAX) break;
+                P.coarse_from = l;
+            }
+        }
         for (int l = 0; l < P.nlevels; ++l) {
             P.lv[l].cell_base = cells;
             const GridDesc &G = P.lv[l];
@@ -1029,21 +1105,25 @@ static int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long 
     GPSCAL_HIP(ctx, hipMemcpyAsync(gs.pairs.p, gs.hpairs.data(), sizeof(PairDesc) * npairs, hipMemcpyHostToDevice,
                                    ctx->stream));
     DevBuf<unsigned> counts;
-    GPSCAL_HIP(ctx, counts.alloc((size_t)cells + 1));
+    GPSCAL_HIP(ctx, counts.alloc_async((size_t)cells + 1, ctx->stream));
     GPSCAL_HIP(ctx, gs.cell_start_buf.alloc((size_t)cells + 1 + 8));
     GPSCAL_HIP(ctx, hipMemsetAsync(gs.cell_start_buf.p, 0, sizeof(unsigned) * ((size_t)cells + 9), ctx->stream));
     gs.cell_start = gs.cell_start_buf.p + 4;
     GPSCAL_HIP(ctx, gs.sorted.alloc((size_t)sorted_total));
     GPSCAL_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
     if (npairs > 0 && mmax > 0) {
-        int gxf = std::max(1, std::min(div_up(mmax, BLOCK), 1024));
-        hipLaunchKernelGGL(grid_fill_kernel<0>, dim3(gxf, npairs), dim3(BLOCK), 0, ctx->stream, gs.pairs.p,
-                           gs.pts4.p, counts.p, (const unsigned *)nullptr, (float4 *)nullptr);
+        int maxlev = 1;
+        for (auto &P : gs.hpairs) maxlev = std::max(maxlev, P.nlevels);
+        DevBuf<unsigned> ranks;
+        GPSCAL_HIP(ctx, ranks.alloc_async((size_t)total * maxlev, ctx->stream));
+        hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(mmax, GC_CHUNK), npairs), dim3(BLOCK), 0, ctx->stream,
+                           gs.pairs.p, gs.pts4.p, counts.p, ranks.p, total);
         int rc = exclusive_scan(ctx, counts.p, gs.cell_start, cells + 1);
         if (rc) return rc;
-        GPSCAL_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
-        hipLaunchKernelGGL(grid_fill_kernel<1>, dim3(gxf, npairs), dim3(BLOCK), 0, ctx->stream, gs.pairs.p,
-                           gs.pts4.p, counts.p, gs.cell_start, gs.sorted.p);
+        int gxf = std::max(1, std::min(div_up(mmax, BLOCK), 1024));
+        hipLaunchKernelGGL(grid_scatter_kernel, dim3(gxf, npairs), dim3(BLOCK), 0, ctx->stream, gs.pairs.p,
+                           gs.pts4.p, ranks.p, gs.cell_start, gs.sorted.p, total);
+        GPSCAL_HIP(ctx, hipGetLastError());
     } else {
         GPSCAL_HIP(ctx, hipMemsetAsync(gs.cell_start, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
     }
