@@ -10,7 +10,8 @@ EXPORTS = [
     "gpscal_last_error", "gpscal_device_info",
     "gpscal_weights_speed", "gpscal_weights_irls",
     "gpscal_track_fit", "gpscal_track_fit_batched", "gpscal_long_segment", "gpscal_long_segment_batched",
-    "gpscal_wgs_to_enu", "gpscal_enu_to_wgs", "gpscal_gps_to_enu", "gpscal_height_compensate",
+    "gpscal_wgs_to_enu", "gpscal_enu_to_wgs", "gpscal_gps_to_enu", "gpscal_gps_to_enu_batched",
+    "gpscal_height_compensate",
     "gpscal_knn_build", "gpscal_knn_search", "gpscal_knn_free",
     "gpscal_scan_batch_create", "gpscal_scan_batch_set_pose", "gpscal_scan_batch_icp",
     "gpscal_scan_batch_correspondences", "gpscal_scan_batch_build_seconds", "gpscal_scan_batch_destroy",
@@ -74,6 +75,7 @@ def load():
     L.gpscal_wgs_to_enu.argtypes = [vp, i, i, dp, dp, i, dp]
     L.gpscal_enu_to_wgs.argtypes = [vp, i, i, dp, i, dp, dp]
     L.gpscal_gps_to_enu.argtypes = [vp, i, i, dp, dp, dp, i, dp, i, dp, C.POINTER(i)]
+    L.gpscal_gps_to_enu_batched.argtypes = [vp, i, i, dp, dp, dp, ip, dp, ip, i, dp, ip]
     L.gpscal_height_compensate.argtypes = [vp, dp, i, dp]
     L.gpscal_knn_build.argtypes = [vp, fp, i, i, C.c_float, C.POINTER(vp)]
     L.gpscal_knn_search.argtypes = [vp, fp, i, i, i, ip, fp]

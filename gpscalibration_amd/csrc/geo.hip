@@ -14,6 +14,8 @@
 // band number from the first fix only (gps_process.cc:869-877).
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace gpscal {
 
 constexpr double REF_PI = 3.141592653589;
@@ -201,6 +203,52 @@ __global__ void interp_kernel(const double *__restrict__ xy, const double *__res
     atomicAdd(n_kept, 1);
 }
 
+// Batched form: segment s owns fixes [goff[s], goff[s+1]) and stamps [soff[s], soff[s+1]).
+// The band number is taken from each segment's first fix, as one GPSToENU call per segment
+// would (gps_process.cc:869-877).  Dropped stamps (after the segment's last fix) are only
+// ever a suffix of the segment: kept[s] counts the survivors.
+__global__ void wgs_to_enu_batched_kernel(int method, int band_type, const double *__restrict__ lat,
+                                          const double *__restrict__ lon, const int *__restrict__ goff, int nseg,
+                                          double *__restrict__ xy)
+{
+    const int s = blockIdx.y;
+    const int g0 = goff[s], ng = goff[s + 1] - g0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ng; i += gridDim.x * blockDim.x) {
+        int band = sticky_band(lon + g0, i, band_type);
+        double x, y;
+        project_fwd(method, band_type, band, lat[g0 + i], lon[g0 + i], x, y);
+        xy[2 * (size_t)(g0 + i)] = x;
+        xy[2 * (size_t)(g0 + i) + 1] = y;
+    }
+}
+
+__global__ void interp_batched_kernel(const double *__restrict__ xy, const double *__restrict__ gt,
+                                      const int *__restrict__ goff, const double *__restrict__ slam,
+                                      const int *__restrict__ soff, double *__restrict__ enu,
+                                      int *__restrict__ kept)
+{
+    const int s = blockIdx.y;
+    const int g0 = goff[s], ng = goff[s + 1] - g0, r0 = soff[s], nr = soff[s + 1] - r0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nr; k += gridDim.x * blockDim.x) {
+        const size_t r = (size_t)(r0 + k);
+        const double tr = slam[4 * r + 3];
+        if (ng < 2 || tr > gt[g0 + ng - 1]) continue;
+        int lo = 0, hi = ng - 2;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (gt[g0 + mid + 1] >= tr) hi = mid; else lo = mid + 1;
+        }
+        const size_t a = (size_t)(g0 + lo);
+        const double s1 = gt[a], s2 = gt[a + 1], s3 = s2 - s1;
+        const double c1 = (tr - s1) / s3, c2 = 1.0 - c1;
+        enu[4 * r + 0] = c1 * xy[2 * (a + 1)] + c2 * xy[2 * a];
+        enu[4 * r + 1] = c1 * xy[2 * (a + 1) + 1] + c2 * xy[2 * a + 1];
+        enu[4 * r + 2] = slam[4 * r + 2];
+        enu[4 * r + 3] = tr;
+        atomicAdd(&kept[s], 1);
+    }
+}
+
 }  // namespace gpscal
 
 using namespace gpscal;
@@ -289,5 +337,48 @@ extern "C" int gpscal_gps_to_enu(gpscal_ctx *ctx, int method, int band_type, con
     GPSCAL_HIP(ctx, o.commit(ctx, &sync, (size_t)k * 4));
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_out = k;
+    return GPSCAL_OK;
+}
+
+extern "C" int gpscal_gps_to_enu_batched(gpscal_ctx *ctx, int method, int band_type, const double *lat,
+                                         const double *lon, const double *gps_t, const int *gps_off,
+                                         const double *slam, const int *slam_off, int nseg, double *enu, int *n_out)
+{
+    int rc = check_proj(ctx, method, band_type);
+    if (rc) return rc;
+    if (!lat || !lon || !gps_t || !gps_off || !slam || !slam_off || !enu || !n_out || nseg < 1)
+        return fail(ctx, GPSCAL_EINVAL, "gpscal_gps_to_enu_batched: bad argument");
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    const int ngps = gps_off[nseg], nslam = slam_off[nseg];
+    if (ngps < 1 || nslam < 1) return fail(ctx, GPSCAL_EINVAL, "gpscal_gps_to_enu_batched: empty input");
+    int gmax = 1, smax = 1;
+    for (int s = 0; s < nseg; ++s) {
+        gmax = std::max(gmax, gps_off[s + 1] - gps_off[s]);
+        smax = std::max(smax, slam_off[s + 1] - slam_off[s]);
+    }
+    InArg<double> a, b, t, sl;
+    InArg<int> go, so;
+    OutArg<double> o;
+    OutArg<int> ko;
+    DevBuf<double> xy;
+    GPSCAL_HIP(ctx, a.bind(ctx, lat, ngps));
+    GPSCAL_HIP(ctx, b.bind(ctx, lon, ngps));
+    GPSCAL_HIP(ctx, t.bind(ctx, gps_t, ngps));
+    GPSCAL_HIP(ctx, sl.bind(ctx, slam, (size_t)nslam * 4));
+    GPSCAL_HIP(ctx, go.bind(ctx, gps_off, nseg + 1));
+    GPSCAL_HIP(ctx, so.bind(ctx, slam_off, nseg + 1));
+    GPSCAL_HIP(ctx, o.bind(ctx, enu, (size_t)nslam * 4));
+    GPSCAL_HIP(ctx, ko.bind(ctx, n_out, nseg));
+    GPSCAL_HIP(ctx, xy.alloc_async((size_t)ngps * 2, ctx->stream));
+    GPSCAL_HIP(ctx, hipMemsetAsync(ko.dev, 0, sizeof(int) * nseg, ctx->stream));
+    hipLaunchKernelGGL(wgs_to_enu_batched_kernel, dim3(div_up(gmax, 256), nseg), dim3(256), 0, ctx->stream, method,
+                       band_type, a.dev, b.dev, go.dev, nseg, xy.p);
+    hipLaunchKernelGGL(interp_batched_kernel, dim3(div_up(smax, 256), nseg), dim3(256), 0, ctx->stream, xy.p, t.dev,
+                       go.dev, sl.dev, so.dev, o.dev, ko.dev);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    bool sync = true;
+    GPSCAL_HIP(ctx, o.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, ko.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GPSCAL_OK;
 }

@@ -35,7 +35,11 @@ void GPSPro::setMethod(std::string m)
     method = m;
 }
 std::string GPSPro::getGPSPath() { return originalGPSPath; }
-void GPSPro::setGPSPath(std::string p) { originalGPSPath = p; }
+void GPSPro::setGPSPath(std::string p)
+{
+    originalGPSPath = p;
+    logLoaded = false;
+}
 void GPSPro::setKMLConfigPath(std::string p) { kmlConfigPath = p; }
 
 // ------------------------------------------------------------------ ingest
@@ -165,6 +169,100 @@ std::vector<COORDXYZT> GPSPro::GPSToENU(std::vector<COORDXYZT> slamTrack)
                             &n_out),
           "gpscal_gps_to_enu");
     out.resize(n_out);
+    return out;
+}
+
+bool GPSPro::loadLog()
+{
+    if (logLoaded) return true;
+    // every line of the log, window test disabled (start = -inf, end = +inf would stop at
+    // nothing): parse with the widest window the (long) casts allow
+    logLat.clear();
+    logLon.clear();
+    logT.clear();
+    std::ifstream in(originalGPSPath.c_str());
+    if (!in.is_open()) {
+        printf("open %s error\n", originalGPSPath.c_str());
+        return false;
+    }
+    std::string line;
+    bool first = true;
+    while (std::getline(in, line)) {
+        if (line.size() >= IMSDLEN) break;
+        Fields F(line);
+        if (first) {
+            first = false;
+            if (F.f.size() < 2 || strcmp(F.f[1], "$GPRMC") != 0) {
+                printf("[WARNING] The current version does not support the current GPS format\n");
+                break;
+            }
+        }
+        double stamp = 0, la = 90, lo = 180;
+        if (!F.f.empty()) stamp = atof(F.f[0]);
+        const bool novalid = F.f.size() >= 4 && strcmp(F.f[3], "V") == 0;
+        if (!novalid) {
+            if (F.f.size() >= 5) la = ddmm_to_deg(F.f[4]);
+            if (F.f.size() >= 6 && strcmp(F.f[5], "S") == 0) la = 0 - la;
+            if (F.f.size() >= 7) lo = ddmm_to_deg(F.f[6]);
+            if (F.f.size() >= 8 && strcmp(F.f[7], "W") == 0) lo = 0 - lo;
+        }
+        logLat.push_back(la);
+        logLon.push_back(lo);
+        logT.push_back(stamp);
+    }
+    logLoaded = true;
+    return true;
+}
+
+void GPSPro::window(double startTime, double endTime, std::vector<double> &lat, std::vector<double> &lon,
+                    std::vector<double> &t) const
+{
+    // the scan of getGPRMCFormat (gps_process.cc:167-227) over the cached lines
+    for (size_t i = 0; i < logT.size(); ++i) {
+        const double stamp = logT[i];
+        if ((long)stamp >= (long)(startTime - 1) && (long)stamp <= (long)(endTime + 1)) {
+            lat.push_back(logLat[i]);
+            lon.push_back(logLon[i]);
+            t.push_back(stamp);
+        }
+        if (!(stamp < endTime + 1)) break;
+    }
+}
+
+std::vector<std::vector<COORDXYZT> > GPSPro::GPSToENUBatch(const std::vector<std::vector<COORDXYZT> > &tracks)
+{
+    std::vector<std::vector<COORDXYZT> > out(tracks.size());
+    if (tracks.empty() || !loadLog()) return out;
+    std::vector<double> lat, lon, t;
+    std::vector<COORDXYZT> slam;
+    std::vector<int> goff(1, 0), soff(1, 0), which;
+    for (size_t s = 0; s < tracks.size(); ++s) {
+        if (tracks[s].empty()) continue;
+        std::vector<double> la, lo, tt;
+        window(tracks[s].front().t, tracks[s].back().t, la, lo, tt);
+        if (tt.empty()) {
+            printf("WARN: cannot find GPS information corresponding to slam track time,please check GPS original file.\n");
+            continue;
+        }
+        gpsProcess(la, lo, tt);
+        lat.insert(lat.end(), la.begin(), la.end());
+        lon.insert(lon.end(), lo.begin(), lo.end());
+        t.insert(t.end(), tt.begin(), tt.end());
+        slam.insert(slam.end(), tracks[s].begin(), tracks[s].end());
+        goff.push_back((int)t.size());
+        soff.push_back((int)slam.size());
+        which.push_back((int)s);
+    }
+    const int nseg = (int)which.size();
+    if (nseg == 0) return out;
+    std::vector<COORDXYZT> enu(slam.size());
+    std::vector<int> kept(nseg, 0);
+    check(gpscal_gps_to_enu_batched(default_ctx(), method == "UTM" ? GPSCAL_METHOD_UTM : GPSCAL_METHOD_GAUSS, type,
+                                    lat.data(), lon.data(), t.data(), goff.data(), &slam[0].x, soff.data(), nseg,
+                                    &enu[0].x, kept.data()),
+          "gpscal_gps_to_enu_batched");
+    for (int k = 0; k < nseg; ++k)
+        out[which[k]].assign(enu.begin() + soff[k], enu.begin() + soff[k] + kept[k]);
     return out;
 }
 

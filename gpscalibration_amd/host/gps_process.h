@@ -21,6 +21,11 @@ public:
     // GPS coordinate -> ENU at the SLAM stamps (gps_process.cc:476-521).  Returns an empty
     // vector (the reference exit(0)s) when the log has no fix for the track's time span.
     std::vector<COORDXYZT> GPSToENU(std::vector<COORDXYZT> slamTrack);
+    // The same for many segments with ONE device call; out[s] == GPSToENU(tracks[s]).  The log
+    // is parsed once and cached (the reference re-opens and re-parses it per segment,
+    // gps_process.cc:113-159); every segment still gets its own time window and its own
+    // dropout fill, so the numbers are those of per-segment calls.
+    std::vector<std::vector<COORDXYZT> > GPSToENUBatch(const std::vector<std::vector<COORDXYZT> > &tracks);
     // ENU -> WGS84 + 50 m colour segments (gps_process.cc:374-386, 600-626, 1010-1058)
     int ENUToGPS(std::vector<COORDXYZTW> enuCoor, std::vector<std::pair<double, double> > &WGSBL,
                  std::vector<double> &altitude, std::vector<std::pair<int, std::string> > &segmentColor);
@@ -40,5 +45,11 @@ private:
     std::string originalGPSPath;
     std::string kmlConfigPath;
     std::vector<std::string> readKMLParameter();
+    // parsed log (all lines, sentinel for 'V'), in file order; stamp 0 for blank lines
+    bool logLoaded = false;
+    std::vector<double> logLat, logLon, logT;
+    bool loadLog();
+    void window(double startTime, double endTime, std::vector<double> &lat, std::vector<double> &lon,
+                std::vector<double> &t) const;
 };
 #endif

@@ -22,9 +22,11 @@ void LongDistanceTrackProcess::processBatch(const std::vector<std::vector<COORDX
     // speed-weight -> fit -> 5 x IRLS chain of every segment in one launch.
     std::vector<COORDXYZT> slam, enu;
     std::vector<int> off(1, 0);
-    for (const auto &trk : tracks) {
+    const std::vector<std::vector<COORDXYZT> > enus = gps_.GPSToENUBatch(tracks);
+    for (size_t k = 0; k < tracks.size(); ++k) {
+        const auto &trk = tracks[k];
         if (trk.empty()) continue;
-        std::vector<COORDXYZT> e = gps_.GPSToENU(trk);
+        const std::vector<COORDXYZT> &e = enus[k];
         if (e.empty()) throw std::runtime_error("WARN: cannot find GPS information corresponding to slam track time");
         // interPolate drops stamps after the last fix (gps_process.cc:99): keep the matched prefix
         slam.insert(slam.end(), trk.begin(), trk.begin() + e.size());

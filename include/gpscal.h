@@ -140,6 +140,15 @@ int gpscal_gps_to_enu(gpscal_ctx *ctx, int method, int band_type,
                       const double *lat, const double *lon,
                       const double *gps_t, int ngps, const double *slam_xyzt,
                       int nslam, double *enu_xyzt, int *n_out);
+/* The same for nseg segments in one launch (what nseg GPSToENU calls do): segment s owns
+ * fixes [gps_off[s], gps_off[s+1]) -- its own time window of the log, gap-filled on its
+ * own -- and stamps [slam_off[s], slam_off[s+1]).  enu rows are written at the stamps'
+ * positions; n_out[s] = stamps of segment s that survived (a prefix of the segment). */
+int gpscal_gps_to_enu_batched(gpscal_ctx *ctx, int method, int band_type,
+                              const double *lat, const double *lon,
+                              const double *gps_t, const int *gps_off,
+                              const double *slam_xyzt, const int *slam_off,
+                              int nseg, double *enu_xyzt, int *n_out);
 /* Replaces SaveTrailWithTimeTotxt's height compensation (TM:116-157) for a
  * whole pose chain: in n x {px,py,pz,t} in LOAM axes, out n COORDXYZT. */
 int gpscal_height_compensate(gpscal_ctx *ctx, const double *loam_xyzt, int n,
