@@ -4,6 +4,7 @@
 //  :600-626 + :692-756 colour segments, :629-689 kml_config.xml, :759-847 KML).
 #include "gps_process.h"
 
+#include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -357,46 +358,66 @@ std::vector<std::string> GPSPro::readKMLParameter()
     return cfg;
 }
 
+namespace {
+// "%.15g" of ofstream::precision(15) (gps_process.cc:769), via std::to_chars: the KML of a
+// long run holds millions of numbers and iostream formatting dominated the output stage.
+inline void put_num(std::string &o, double v)
+{
+    char b[40];
+    auto r = std::to_chars(b, b + sizeof b, v, std::chars_format::general, IMDP);
+    o.append(b, r.ptr);
+}
+inline void put_coord(std::string &o, double lon, double lat, double alt)
+{
+    put_num(o, lon);
+    o.push_back(',');
+    put_num(o, lat);
+    o.push_back(',');
+    put_num(o, alt);
+    o.push_back('\n');
+}
+}  // namespace
+
 int GPSPro::createKML(std::string name, std::vector<std::pair<double, double> > WGSBL, std::vector<double> altitude,
                       int flag, std::vector<std::pair<int, std::string> > segmentColor)
 {
     const std::vector<std::string> cfg = readKMLParameter();
-    std::ofstream o(name.c_str());
-    if (!o.is_open()) {
+    FILE *fp = fopen(name.c_str(), "w");
+    if (!fp) {
         printf("open %s error\n", name.c_str());
         return 1;
     }
-    o.precision(IMDP);
-    auto placemark_head = [&]() {
-        o << "<Placemark>\n<styleUrl>" << cfg[2] << "</styleUrl>\n<LineString>\n<extrude>" << cfg[3]
-          << "</extrude>\n<tessellate>" << cfg[4] << "</tessellate>\n<altitudeMode>" << cfg[5]
-          << "</altitudeMode>\n<coordinates>\n";
-    };
-    o << "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n<kml xmlns=\"http://www.opengis.net/kml/2.2\">\n<Document>\n";
+    std::string o;
+    o.reserve(WGSBL.size() * 48 + segmentColor.size() * 400 + 1024);
+    const std::string placemark_head = "<Placemark>\n<styleUrl>" + cfg[2] + "</styleUrl>\n<LineString>\n<extrude>" + cfg[3] +
+                                       "</extrude>\n<tessellate>" + cfg[4] + "</tessellate>\n<altitudeMode>" + cfg[5] +
+                                       "</altitudeMode>\n<coordinates>\n";
+    o += "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n<kml xmlns=\"http://www.opengis.net/kml/2.2\">\n<Document>\n";
     if (flag == 0) {
-        o << "<name>original GPS</name>\n<description>original GPS</description>\n";
-        o << "<Style id=\"" << cfg[0] << "\">\n<LineStyle>\n<color>7fFF00FF</color>\n<width>" << cfg[1]
-          << "</width>\n</LineStyle>\n<PolyStyle>\n<color>7fFF00FF</color>\n</PolyStyle>\n</Style>\n";
-        placemark_head();
+        o += "<name>original GPS</name>\n<description>original GPS</description>\n";
+        o += "<Style id=\"" + cfg[0] + "\">\n<LineStyle>\n<color>7fFF00FF</color>\n<width>" + cfg[1] +
+             "</width>\n</LineStyle>\n<PolyStyle>\n<color>7fFF00FF</color>\n</PolyStyle>\n</Style>\n";
+        o += placemark_head;
         for (size_t i = 0; i < WGSBL.size() && i < altitude.size(); ++i)
-            o << WGSBL[i].first << ',' << WGSBL[i].second << ',' << altitude[i] << '\n';
-        o << "</coordinates>\n</LineString></Placemark>\n";
+            put_coord(o, WGSBL[i].first, WGSBL[i].second, altitude[i]);
+        o += "</coordinates>\n</LineString></Placemark>\n";
     } else {
-        o << "<name>calibrated GPS</name>\n<description>calibrated GPS</description>\n";
+        o += "<name>calibrated GPS</name>\n<description>calibrated GPS</description>\n";
         size_t ic = 0;
         for (size_t k = 0; k < segmentColor.size(); ++k) {
-            o << "<Style id=\"" << cfg[0] << "\">\n<LineStyle>\n<color>7f" << segmentColor[k].second
-              << "</color>\n<width>" << cfg[1] << "</width>\n</LineStyle>\n<PolyStyle>\n<color>"
-              << segmentColor[k].second << "</color>\n</PolyStyle>\n</Style>\n";
-            placemark_head();
+            o += "<Style id=\"" + cfg[0] + "\">\n<LineStyle>\n<color>7f" + segmentColor[k].second + "</color>\n<width>" +
+                 cfg[1] + "</width>\n</LineStyle>\n<PolyStyle>\n<color>" + segmentColor[k].second +
+                 "</color>\n</PolyStyle>\n</Style>\n";
+            o += placemark_head;
             // the reference's loop tests its config cursor (== 6) against altitude.size() and
             // stops BEFORE segment end: the last point of the track is never written (gps_process.cc:832)
             for (; ic < (size_t)segmentColor[k].first && 6 < altitude.size(); ++ic)
-                o << WGSBL[ic].first << ',' << WGSBL[ic].second << ',' << altitude[ic] << '\n';
-            o << "</coordinates>\n</LineString></Placemark>\n";
+                put_coord(o, WGSBL[ic].first, WGSBL[ic].second, altitude[ic]);
+            o += "</coordinates>\n</LineString></Placemark>\n";
         }
     }
-    o << "</Document></kml>\n";
-    o.close();
+    o += "</Document></kml>\n";
+    fwrite(o.data(), 1, o.size(), fp);
+    fclose(fp);
     return 0;
 }

@@ -2,6 +2,7 @@
 // long_distance_track_process.cpp:21-88, short_distance_track_process.cpp:39-158,234-245).
 #include "track_process.h"
 
+#include <algorithm>
 #include <cmath>
 #include <stdexcept>
 
@@ -46,13 +47,26 @@ void LongDistanceTrackProcess::processBatch(const std::vector<std::vector<COORDX
     }
 }
 
+void ShortDistanceTrackProcess::setGPS(const std::vector<COORDXYZTW> &gps)
+{
+    gps_ = gps;
+    gps_sorted_ = std::is_sorted(gps_.begin(), gps_.end(), [](const COORDXYZTW &a, const COORDXYZTW &b) { return a.t < b.t; });
+}
+
 void ShortDistanceTrackProcess::getGPS(const std::vector<COORDXYZTW> &gps, const std::vector<COORDXYZT> &slamTrack,
                                        std::vector<COORDXYZT> &slamWithGPS, std::vector<COORDXYZT> &GPSWithSlam,
-                                       std::vector<double> &weight)
+                                       std::vector<double> &weight, bool gpsTimeOrdered)
 {
-    // two-pointer match on |dt| < 1e-6 (short_distance_track_process.cpp:39-70)
-    size_t i = 0;
-    for (size_t g = 0; g < gps.size() && i < slamTrack.size();) {
+    // two-pointer match on |dt| < 1e-6 (short_distance_track_process.cpp:39-70).  The
+    // reference walks the whole-run track from its first sample for every segment; on a
+    // time-ordered track (long segments are appended in time order, LD:28-37) nothing
+    // before the segment's first stamp can match, so the walk starts there.
+    size_t i = 0, g0 = 0;
+    if (!slamTrack.empty() && gpsTimeOrdered) {
+        const double t0 = slamTrack[0].t - 0.000001;
+        g0 = std::lower_bound(gps.begin(), gps.end(), t0, [](const COORDXYZTW &a, double t) { return a.t < t; }) - gps.begin();
+    }
+    for (size_t g = g0; g < gps.size() && i < slamTrack.size();) {
         const double dt = gps[g].t - slamTrack[i].t;
         if (std::fabs(dt) < 0.000001) {
             COORDXYZT p = {gps[g].x, gps[g].y, gps[g].z, gps[g].t};
@@ -85,7 +99,15 @@ void ShortDistanceTrackProcess::merge(const std::vector<COORDXYZT> &seg, const s
     std::vector<size_t> lost;
     const size_t na = out_.size();
     double c1 = 0.0, c2 = 0.0;
-    for (size_t a = 0; a < na; ++a) {
+    // Samples before the first match only ever enter the "lost" list that the first match
+    // clears (SD:104-107) -- or, without any match, that SD:137-140 clears -- so on a
+    // time-ordered track the scan can start at the segment's first stamp.
+    size_t a0 = 0;
+    if (!seg.empty() && sorted_) {
+        const double t0 = seg[0].t - 0.000001;
+        a0 = std::lower_bound(out_.begin(), out_.end(), t0, [](const COORDXYZTW &p, double t) { return p.t < t; }) - out_.begin();
+    }
+    for (size_t a = a0; a < na; ++a) {
         const bool match = it < seg.size() && std::fabs(out_[a].t - seg[it].t) < 0.000001;
         if (!match) {
             lost.push_back(a);
@@ -119,6 +141,9 @@ void ShortDistanceTrackProcess::merge(const std::vector<COORDXYZT> &seg, const s
         out_.push_back(p);
     }
     for (size_t k = lost.size(); k-- > 0;) out_.erase(out_.begin() + lost[k]);
+    // keep track of time order for the shortcut above
+    if (sorted_)
+        for (size_t k = (a0 > 0 ? a0 : 1); k < out_.size() && sorted_; ++k) sorted_ = out_[k - 1].t <= out_[k].t;
 }
 
 void ShortDistanceTrackProcess::process(const std::vector<COORDXYZT> &slamTrack)
@@ -138,7 +163,7 @@ void ShortDistanceTrackProcess::processBatch(const std::vector<std::vector<COORD
     for (const auto &trk : tracks) {
         std::vector<COORDXYZT> s, g;
         std::vector<double> ww;
-        getGPS(gps_, trk, s, g, ww);
+        getGPS(gps_, trk, s, g, ww, gps_sorted_);
         if (s.empty()) continue;
         slam.insert(slam.end(), s.begin(), s.end());
         enu.insert(enu.end(), g.begin(), g.end());

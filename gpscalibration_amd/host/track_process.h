@@ -26,7 +26,7 @@ private:
 class ShortDistanceTrackProcess {
 public:
     // gps = the whole-run ENU GPS + weights received on gps_weight
-    void setGPS(const std::vector<COORDXYZTW> &gps) { gps_ = gps; }
+    void setGPS(const std::vector<COORDXYZTW> &gps);
     void process(const std::vector<COORDXYZT> &slamTrack);  // short_distance_track_process.cpp:236-244
     void processBatch(const std::vector<std::vector<COORDXYZT> > &slamTracks);
     const std::vector<COORDXYZTW> &result() const { return out_; }
@@ -34,10 +34,12 @@ public:
     // exposed for tests
     static void getGPS(const std::vector<COORDXYZTW> &gps, const std::vector<COORDXYZT> &slamTrack,
                        std::vector<COORDXYZT> &slamWithGPS, std::vector<COORDXYZT> &GPSWithSlam,
-                       std::vector<double> &weight);
+                       std::vector<double> &weight, bool gpsTimeOrdered = false);
     void merge(const std::vector<COORDXYZT> &slamTrack, const std::vector<double> &weight);
 
 private:
     std::vector<COORDXYZTW> gps_, out_;
+    bool gps_sorted_ = false;  // gps_ is in time order (lets getGPS start at the segment's first stamp)
+    bool sorted_ = true;  // out_ is in time order (lets merge() skip the untouched head)
 };
 #endif
