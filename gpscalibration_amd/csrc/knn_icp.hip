@@ -584,11 +584,13 @@ __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__res
             const bool pass = ((lanemask >> r) & 1u) && rb2 * 0.99999f <= B.worst();
             if (__ballot(pass) == 0ull) continue;  // an earlier row tightened the bound
             const unsigned c0 = has_l ? q.a : q.b, c1 = q.b, c2 = q.c, c3 = has_r ? q.d : q.c;
-            scan_runs(B, pass, sorted, c1, c2, px, py, pz);
-            const bool pl = pass && c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst();
-            const bool pr = pass && c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst();
-            if (__ballot(pl) != 0ull) scan_runs(B, pl, sorted, c0, c1, px, py, pz);
-            if (__ballot(pr) != 0ull) scan_runs(B, pr, sorted, c2, c3, px, py, pz);
+            // left | own | right cells are one contiguous run: cells whose face is already
+            // within reach are scanned together with the own cell (one pass of loads instead
+            // of three dependent ones); a neighbour ruled out now stays ruled out, the bound
+            // only tightens.
+            const bool pl0 = pass && c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst();
+            const bool pr0 = pass && c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst();
+            scan_runs(B, pass, sorted, pl0 ? c0 : c1, pr0 ? c3 : c2, px, py, pz);
         }
         if (act && B.worst() <= C.settled_r2(G)) todo = false;
     }
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
 // and measured SLOWER than this pruned global path (the box holds ~3.3 points per
 // query against ~2.4 the query reads); see DESIGN.md.
 template <int QPT, bool WEIGHTED>
-__global__ __launch_bounds__(BLOCK) void icp_step_kernel(
+__global__ __launch_bounds__(BLOCK, 7) void icp_step_kernel(
     const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
     const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
     const float4 *__restrict__ nbr, const float2 *__restrict__ pt_r2, const unsigned *__restrict__ cell_start,
