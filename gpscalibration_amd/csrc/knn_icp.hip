@@ -705,7 +705,7 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
 // and measured SLOWER than this pruned global path (the box holds ~3.3 points per
 // query against ~2.4 the query reads); see DESIGN.md.
 template <int QPT, bool WEIGHTED>
-__global__ __launch_bounds__(BLOCK, 7) void icp_step_kernel(
+__global__ __launch_bounds__(BLOCK) void icp_step_kernel(
     const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
     const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
     const float4 *__restrict__ nbr, const float2 *__restrict__ pt_r2, const unsigned *__restrict__ cell_start,
