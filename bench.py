@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-track", action="store_true", help="skip the bag->KML (track path) section")
+    ap.add_argument("--no-single-pair", action="store_true",
+                    help="skip the single-pair latency probe (keeps rocprof's per-kernel average to the batch launches)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -203,19 +205,21 @@ def main():
             except Exception:  # noqa: BLE001
                 traffic = None
         # ---- single-pair latency-bound rate, for DESIGN.md (not `value`)
-        off1 = np.array([0, n], dtype=np.int64)
-        sb1 = ctx.scan_batch(d_tg[:n], off1, d_sr[:n], off1)
-        for _ in range(2):
-            sb1.set_pose(None)
-            sb1.icp(args.iters, want_err=False, T_out=d_T[:1])
-        ctx.sync()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            sb1.set_pose(None)
-            sb1.icp(args.iters, want_err=False, T_out=d_T[:1])
-        ctx.sync()
-        single = 5 * args.iters / (time.perf_counter() - t1)
-        sb1.close()
+        single = None
+        if not args.no_single_pair:
+            off1 = np.array([0, n], dtype=np.int64)
+            sb1 = ctx.scan_batch(d_tg[:n], off1, d_sr[:n], off1)
+            for _ in range(2):
+                sb1.set_pose(None)
+                sb1.icp(args.iters, want_err=False, T_out=d_T[:1])
+            ctx.sync()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                sb1.set_pose(None)
+                sb1.icp(args.iters, want_err=False, T_out=d_T[:1])
+            ctx.sync()
+            single = 5 * args.iters / (time.perf_counter() - t1)
+            sb1.close()
         out = {
             "metric": "ICP iterations/sec (64k-pt scans)", "value": value, "unit": "ICP iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
