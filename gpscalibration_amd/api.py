@@ -171,6 +171,39 @@ class Context:
         self._ck(self._L.gpscal_height_compensate(self._h, _ptr(p), len(p), _ptr(out)), "height_compensate")
         return out
 
+    # --------------------------------------------------------------- LOAM
+    def loam_odometry(self, sharp, flat, corner_last, surf_last, transform_in=None, transform_sum_in=None):
+        """Batched laserOdometry iteration loop.  Each cloud argument is a list of [n,4] float32 arrays
+        (one per sweep).  Returns (transform[nsweeps,6], iters, nsel, transform_sum | None)."""
+        ns = len(sharp)
+
+        def pack(lst):
+            off = np.zeros(ns + 1, dtype=np.int32)
+            off[1:] = np.cumsum([len(a) for a in lst])
+            data = np.ascontiguousarray(np.concatenate(lst) if off[-1] else np.zeros((1, 4)), dtype=np.float32)
+            return data, off
+        sh, sho = pack(sharp)
+        fl, flo = pack(flat)
+        cl, clo = pack(corner_last)
+        sl, slo = pack(surf_last)
+        tin = np.zeros((ns, 6), dtype=np.float32) if transform_in is None else np.ascontiguousarray(transform_in, dtype=np.float32)
+        tout = np.empty((ns, 6), dtype=np.float32)
+        iters = np.empty(ns, dtype=np.int32)
+        nsel = np.empty(ns, dtype=np.int32)
+        sin = None if transform_sum_in is None else np.ascontiguousarray(transform_sum_in, dtype=np.float32)
+        sout = None if sin is None else np.empty((ns, 6), dtype=np.float32)
+        self._ck(self._L.gpscal_loam_odometry_batched(self._h, ns, _ptr(sh), _ptr(sho), _ptr(fl), _ptr(flo), _ptr(cl),
+                                                      _ptr(clo), _ptr(sl), _ptr(slo), _ptr(tin), _ptr(tout), _ptr(iters),
+                                                      _ptr(nsel), _ptr(sin), _ptr(sout)), "loam_odometry_batched")
+        return tout, iters, nsel, sout
+
+    def loam_transform(self, transform6, pts_xyzi, to_end=False):
+        t = np.ascontiguousarray(transform6, dtype=np.float32)
+        p = np.ascontiguousarray(pts_xyzi, dtype=np.float32)
+        out = np.empty_like(p)
+        self._ck(self._L.gpscal_loam_transform(self._h, _ptr(t), _ptr(p), len(p), _ptr(out), int(to_end)), "loam_transform")
+        return out
+
     # ------------------------------------------------------------ factories
     def knn_index(self, xyz, stride_bytes=12, cell_size=0.0):
         return KnnIndex(self, xyz, stride_bytes, cell_size)

@@ -1,0 +1,38 @@
+// knn_host.hpp -- host side of the grid index shared between translation units.
+#pragma once
+#include <vector>
+
+#include "common.hpp"
+#include "knn_device.hpp"
+
+namespace gpscal {
+
+struct GridSet {
+    gpscal_ctx *ctx = nullptr;
+    int npairs = 0;
+    std::vector<long long> off;  // npairs + 1 point offsets
+    std::vector<PairDesc> hpairs;
+    DevBuf<PairDesc> pairs;
+    DevBuf<float4> pts4;    // caller order
+    DevBuf<float4> sorted;  // all (pair, level) blocks
+    DevBuf<float4> nbr;     // per original point: its 4 nearest other points (lazy, ICP only)
+    DevBuf<float2> pt_r2;   // per original point: (r_a^2, r_b^2) certified radii
+    DevBuf<unsigned> cell_start_buf;  // 4 pad + cells + 1 + 4 pad
+    unsigned *cell_start = nullptr;
+    long long total_cells = 0, total_sorted = 0;
+};
+
+// Builds the level ladders and the counting-sorted copies for npairs clouds
+// (xyz at `stride` bytes, `off` = npairs+1 point offsets).  max_levels == 1 gives the
+// tiled single-level grouping used for source clouds.
+int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long long *off, int npairs, float cell,
+                int max_levels, GridSet &gs);
+// Neighbour lists + certified radii (ICP only).
+int ensure_safe_radius(gpscal_ctx *ctx, GridSet &gs);
+
+}  // namespace gpscal
+
+struct gpscal_knn_index {
+    gpscal_ctx *ctx;
+    gpscal::GridSet gs;
+};

@@ -21,6 +21,8 @@
 //   pose        double[pairs][16] + float[pairs][12]
 // Roofline: HBM; algorithmic bytes per iteration = 20 n + 12 m.
 #include "common.hpp"
+#include "knn_device.hpp"
+#include "knn_host.hpp"
 #include "svd3.hpp"
 #include "wave_reduce.hpp"
 
@@ -30,69 +32,6 @@
 #include <cstdlib>
 
 namespace gpscal {
-
-constexpr int MAX_LEVELS = 8;
-constexpr int BLOCK = 256;
-constexpr int NACC_PLAIN = 17;   // n, sum p(3), sum q(3), sum p q^T(9), sum dist
-constexpr int NACC_WEIGHTED = 25;  // + sw, sw2, sum w2 p(3), sum w2 q(3) (w-sums replace n)
-
-struct GridDesc {
-    float ox, oy, oz, inv_h;
-    float h, margin;
-    int nx, ny, nz;
-    int tile;  // 1: cells numbered in 8x8 xy tiles (source grouping only, never searched)
-    long long cell_base;
-};
-
-struct PairDesc {
-    long long tgt_off;  // into tgt4
-    long long src_off;  // into src4 / nn arrays / weights
-    int m, n;
-    int nlevels;
-    int pblk_off;  // first partial slot of this pair
-    int pblk_cnt;
-    int coarse_from;  // first level whose cell counters are aggregated in LDS at build time
-    GridDesc lv[MAX_LEVELS];
-};
-
-// ------------------------------------------------------------------ helpers
-
-__device__ __forceinline__ int f2ord(float f)
-{
-    int b = __float_as_int(f);
-    return b >= 0 ? b : b ^ 0x7fffffff;
-}
-__host__ __device__ __forceinline__ float ord2f(int k)
-{
-    int b = k >= 0 ? k : k ^ 0x7fffffff;
-#ifdef __HIP_DEVICE_COMPILE__
-    return __int_as_float(b);
-#else
-    float f;
-    memcpy(&f, &b, 4);
-    return f;
-#endif
-}
-__device__ __forceinline__ bool finite3(float x, float y, float z)
-{
-    return isfinite(x) && isfinite(y) && isfinite(z);
-}
-
-// The squared distance every implementation shares (oracle: orc_sqdist).
-__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz)
-{
-    float dx = ax - bx, dy = ay - by, dz = az - bz;
-    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
-}
-
-// XCD-aware block remap (cdna_hip_programming.md T1, bijective form): logical
-// blocks that are adjacent in memory land on the same XCD, i.e. the same L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk)
-{
-    int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (bid >> 3);
-}
 
 // --------------------------------------------------------------- build path
 
@@ -141,26 +80,6 @@ __global__ void bbox_kernel(const float4 *__restrict__ pts, const long long *__r
             atomicMax(&bbox[b * 6 + 3 + a], f2ord(mx[a]));
         }
     }
-}
-
-__device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n)
-{
-    int c = (int)floorf((p - o) * inv_h);
-    return min(max(c, 0), n - 1);
-}
-
-__device__ __forceinline__ long long cell_of(const GridDesc &G, float x, float y, float z)
-{
-    int cx = cell_coord(x, G.ox, G.inv_h, G.nx);
-    int cy = cell_coord(y, G.oy, G.inv_h, G.ny);
-    int cz = cell_coord(z, G.oz, G.inv_h, G.nz);
-    if (G.tile) {
-        // 8x8 tiles in xy keep 256 consecutive points a compact patch, so the
-        // fused kernel's LDS box stays small
-        const int ntx = (G.nx + 7) >> 3, nty = (G.ny + 7) >> 3;
-        return G.cell_base + ((((long long)cz * nty + (cy >> 3)) * ntx + (cx >> 3)) << 6) + ((cy & 7) << 3) + (cx & 7);
-    }
-    return G.cell_base + ((long long)cz * G.ny + cy) * G.nx + cx;
 }
 
 // Counting sort of every point into every level's cells, in two kernels.
@@ -317,284 +236,6 @@ static int exclusive_scan(gpscal_ctx *ctx, const unsigned *in, unsigned *out, lo
 }
 
 // ------------------------------------------------------------- query path
-
-template <int K>
-struct Best {
-    static constexpr bool COOP = false;  // k > 1: per-lane scanning only
-    float d[K];
-    int i[K];
-    __device__ __forceinline__ void init()
-    {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            d[k] = INFINITY;
-            i[k] = 0x7fffffff;
-        }
-    }
-    __device__ __forceinline__ float worst() const { return d[K - 1]; }
-    __device__ __forceinline__ void consider(float d2, const float4 &c, unsigned)
-    {
-        const int idx = __float_as_int(c.w);
-        if (d2 < d[K - 1] || (d2 == d[K - 1] && idx < i[K - 1])) {
-            if (K > 1) {
-                // a coarser level re-visits the points of the finer ones
-                bool dup = false;
-#pragma unroll
-                for (int s = 0; s < K - 1; ++s) dup |= i[s] == idx;
-                if (dup) return;
-            }
-            d[K - 1] = d2;
-            i[K - 1] = idx;
-#pragma unroll
-            for (int s = K - 1; s > 0; --s) {
-                bool sw = d[s] < d[s - 1] || (d[s] == d[s - 1] && i[s] < i[s - 1]);
-                if (sw) {
-                    float td = d[s]; d[s] = d[s - 1]; d[s - 1] = td;
-                    int ti = i[s]; i[s] = i[s - 1]; i[s - 1] = ti;
-                }
-            }
-        }
-    }
-};
-
-// 1-NN record of the ICP kernel.  (d2, index) live in one 64-bit key -- d2 >= 0, so
-// its float bits order like the value and the key orders exactly like (d2, index):
-// accepting a candidate is one v_cmp_lt_u64 and three v_cndmask.  `pos` is the
-// winner's position in `sorted` (WARM = the warm-start candidate is still best).
-struct BestQ {
-    static constexpr bool COOP = true;  // long runs are scanned by the whole wave
-    static constexpr unsigned WARM = 0xffffffffu;
-    static constexpr unsigned LIST = 0xfffffff0u;  // LIST + j: j-th entry of q0's neighbour list
-    unsigned long long key;
-    unsigned pos;
-    __device__ __forceinline__ void init()
-    {
-        key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, INT_MAX)
-        pos = WARM;
-    }
-    __device__ __forceinline__ float dist2() const { return __uint_as_float((unsigned)(key >> 32)); }
-    __device__ __forceinline__ int index() const { return (int)(unsigned)key; }
-    __device__ __forceinline__ float worst() const { return dist2(); }
-    __device__ __forceinline__ void consider(float d2, const float4 &c, unsigned p)
-    {
-        const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(c.w);
-        if (k2 < key) {
-            key = k2;
-            pos = p;
-        }
-    }
-};
-
-// Four consecutive cell_start entries fetched as ONE 16-byte load (dword aligned).
-struct __attribute__((packed, aligned(4))) CellQuad {
-    unsigned a, b, c, d;
-};
-
-// Candidates [s, e) of `sorted`, scanned by the lane itself with four 16-byte
-// gathers in flight.
-template <class BT>
-__device__ __forceinline__ void scan_short(BT &B, bool act, const float4 *__restrict__ sorted, unsigned s, unsigned e,
-                                           float px, float py, float pz)
-{
-    if (!act) return;
-    for (unsigned j = s; j < e; j += 4) {
-        const unsigned last = e - 1;
-        float4 c0 = sorted[j];
-        float4 c1 = sorted[min(j + 1, last)];
-        float4 c2 = sorted[min(j + 2, last)];
-        float4 c3 = sorted[min(j + 3, last)];
-        B.consider(sqdist(px, py, pz, c0.x, c0.y, c0.z), c0, j);
-        if (j + 1 < e) B.consider(sqdist(px, py, pz, c1.x, c1.y, c1.z), c1, j + 1);
-        if (j + 2 < e) B.consider(sqdist(px, py, pz, c2.x, c2.y, c2.z), c2, j + 2);
-        if (j + 3 < e) B.consider(sqdist(px, py, pz, c3.x, c3.y, c3.z), c3, j + 3);
-    }
-}
-
-constexpr unsigned COOP_MIN = 12;   // runs longer than this are worth the whole wave ...
-constexpr int COOP_MAX_OWNERS = 6;  // ... but only while few lanes have one (owners * L/64 < L/4)
-
-__device__ __forceinline__ float readlane_f(float v, int l)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-
-// Must be reached by all 64 lanes of the wave (wave-uniform control flow).  Short
-// runs are scanned per lane.  A long run (a dense or coarse cell) is scanned by the
-// whole wave for its owner: 64 consecutive candidates per step, one coalesced 1 KiB
-// load instead of 64 dependent gathers by one lane, then a DPP arg-min.
-template <class BT>
-__device__ __forceinline__ void scan_runs(BT &B, bool act, const float4 *__restrict__ sorted, unsigned s, unsigned e,
-                                          float px, float py, float pz)
-{
-    if constexpr (!BT::COOP) {
-        scan_short(B, act, sorted, s, e, px, py, pz);
-    } else {
-        bool lng = act && (e - s) > COOP_MIN;
-        unsigned long long m = __ballot(lng);
-        if (__popcll(m) > COOP_MAX_OWNERS) {  // everybody has work: lanes scan in parallel
-            m = 0ull;
-            lng = false;
-        }
-        scan_short(B, act && !lng, sorted, s, e, px, py, pz);
-        const int lane = threadIdx.x & 63;
-        while (m) {  // wave-uniform
-            const int owner = __builtin_ctzll(m);
-            m &= m - 1;
-            const float qx = readlane_f(px, owner), qy = readlane_f(py, owner), qz = readlane_f(pz, owner);
-            const unsigned ss = __builtin_amdgcn_readlane(s, owner), ee = __builtin_amdgcn_readlane(e, owner);
-            float bd = INFINITY;
-            int bi = 0x7fffffff;
-            unsigned bp = 0;
-            float bx = 0.f, by = 0.f, bz = 0.f;
-            for (unsigned j0 = ss; j0 < ee; j0 += 64) {
-                const unsigned j = j0 + lane;
-                if (j < ee) {
-                    const float4 c = sorted[j];
-                    const float d2 = sqdist(qx, qy, qz, c.x, c.y, c.z);
-                    const int ci = __float_as_int(c.w);
-                    if (d2 < bd || (d2 == bd && ci < bi)) {
-                        bd = d2; bi = ci; bp = j; bx = c.x; by = c.y; bz = c.z;
-                    }
-                }
-            }
-            // (d2 >= 0, index >= 0): the 64-bit key orders exactly like (d2, index)
-            const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bi;
-            const unsigned long long kmin = wave_min_u64(key);
-            const int win = __builtin_ctzll(__ballot(key == kmin));
-            const float wd = readlane_f(bd, win);
-            const float4 wc = make_float4(readlane_f(bx, win), readlane_f(by, win), readlane_f(bz, win),
-                                          __int_as_float(__builtin_amdgcn_readlane(bi, win)));
-            const unsigned wpos = __builtin_amdgcn_readlane(bp, win);
-            if (lane == owner && wd < INFINITY) B.consider(wd, wc, wpos);
-        }
-    }
-}
-
-// Per-query geometry at one grid level.
-struct CellGeo {
-    int cx, cy, cz;
-    float fx0, fx1, fy0, fy1, fz0, fz1;  // distances to the faces of the own cell
-    __device__ __forceinline__ void set(const GridDesc &G, float px, float py, float pz)
-    {
-        cx = cell_coord(px, G.ox, G.inv_h, G.nx);
-        cy = cell_coord(py, G.oy, G.inv_h, G.ny);
-        cz = cell_coord(pz, G.oz, G.inv_h, G.nz);
-        const float h = G.h;
-        fx0 = px - (G.ox + cx * h); fx1 = (G.ox + (cx + 1) * h) - px;
-        fy0 = py - (G.oy + cy * h); fy1 = (G.oy + (cy + 1) * h) - py;
-        fz0 = pz - (G.oz + cz * h); fz1 = (G.oz + (cz + 1) * h) - pz;
-    }
-    // squared radius inside which this level's 3x3x3 block is exhaustive
-    __device__ __forceinline__ float settled_r2(const GridDesc &G) const
-    {
-        const float h = G.h;
-        float g = INFINITY;
-        if (cx - 1 > 0) g = fminf(g, fx0 + h);
-        if (cx + 1 < G.nx - 1) g = fminf(g, fx1 + h);
-        if (cy - 1 > 0) g = fminf(g, fy0 + h);
-        if (cy + 1 < G.ny - 1) g = fminf(g, fy1 + h);
-        if (cz - 1 > 0) g = fminf(g, fz0 + h);
-        if (cz + 1 < G.nz - 1) g = fminf(g, fz1 + h);
-        g = fmaxf(g - G.margin, 0.f);
-        return g == INFINITY ? INFINITY : g * g * 0.99999f;
-    }
-};
-
-// Exact k-NN of (px,py,pz) in pair P, levels first_level.. fine -> coarse.  MUST be
-// called by all 64 lanes of a wave (act = false for lanes without a query): control
-// flow is wave-uniform so that long runs can be scanned cooperatively.
-// A level's 3x3x3 block of cells settles the query when the k-th best distance is
-// within the distance to the nearest face of the block that still has cells behind
-// it.  The coarsest level has <= 2 cells per axis, so it always settles.  Rows
-// (fixed y,z; x-1..x+1 contiguous in memory) and then single cells are skipped when
-// their nearest face is already farther than the k-th best, so a good starting
-// candidate (the previous iteration's neighbour) removes most of the memory traffic.
-template <class BT>
-__device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__restrict__ sorted,
-                                          const unsigned *__restrict__ cell_start, bool act, float px, float py,
-                                          float pz, BT &B)
-{
-    if (!act) px = py = pz = 0.f;
-    // A lane that already holds a candidate skips the levels that cannot settle it:
-    // level l settles every query whose best is within h_l (the 3x3x3 block reaches
-    // at least one cell beyond the query's own), so the first such level is searched
-    // alone.  Without a candidate (first iteration) the search starts at level 0.
-    int start = 0;
-    {
-        const float w0 = B.worst();
-        if (w0 < INFINITY) {
-            start = P.nlevels - 1;
-            for (int l = P.nlevels - 2; l >= 0; --l) {
-                const float g = P.lv[l].h * 0.999f - P.lv[l].margin;
-                if (g > 0.f && w0 <= g * g) start = l;
-            }
-        }
-    }
-    bool todo = act;
-    for (int l = 0; l < P.nlevels; ++l) {
-        if (__ballot(todo) == 0ull) break;
-        const bool act = todo && l >= start;
-        if (__ballot(act) == 0ull) continue;
-        const GridDesc &G = P.lv[l];
-        CellGeo C;
-        C.set(G, px, py, pz);
-        const float mg = G.margin;
-        const float bxl = fmaxf(C.fx0 - mg, 0.f), bxr = fmaxf(C.fx1 - mg, 0.f);
-        const bool has_l = C.cx > 0, has_r = C.cx + 1 < G.nx;
-        // face distances of the 3 x 3 rows: index 0 = own, 1 = lower, 2 = upper neighbour
-        const float by2[3] = {0.f, fmaxf(C.fy0 - mg, 0.f) * fmaxf(C.fy0 - mg, 0.f),
-                              fmaxf(C.fy1 - mg, 0.f) * fmaxf(C.fy1 - mg, 0.f)};
-        const float bz2[3] = {0.f, fmaxf(C.fz0 - mg, 0.f) * fmaxf(C.fz0 - mg, 0.f),
-                              fmaxf(C.fz1 - mg, 0.f) * fmaxf(C.fz1 - mg, 0.f)};
-        const bool yok[3] = {true, C.cy > 0, C.cy + 1 < G.ny};
-        const bool zok[3] = {true, C.cz > 0, C.cz + 1 < G.nz};
-        // rows this lane (lanemask) / some lane of the wave (wavemask) still has to look
-        // at; bit r = 3*kz + ky
-        unsigned wavemask = 0, lanemask = 0;
-        {
-            const float w0 = B.worst();
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                const bool p = act && yok[r % 3] && zok[r / 3] && (by2[r % 3] + bz2[r / 3]) * 0.99999f <= w0;
-                if (p) lanemask |= 1u << r;
-                if (__ballot(p) != 0ull) wavemask |= 1u << r;
-            }
-        }
-        // cell_start[row-1 .. row+2] of row r: left | own | right cell boundaries.  The
-        // next row's quad is fetched while the current row's candidates are scanned.
-        auto load_quad = [&](int r) -> CellQuad {
-            CellQuad q = {0u, 0u, 0u, 0u};
-            if ((lanemask >> r) & 1u) {
-                const int kz = r / 3, ky = r - 3 * kz;
-                const int zz = C.cz + (kz == 0 ? 0 : (kz == 1 ? -1 : 1)), yy = C.cy + (ky == 0 ? 0 : (ky == 1 ? -1 : 1));
-                const long long row = G.cell_base + ((long long)zz * G.ny + yy) * G.nx + C.cx;
-                q = *reinterpret_cast<const CellQuad *>(cell_start + row - 1);
-            }
-            return q;
-        };
-        CellQuad nxt = {0u, 0u, 0u, 0u};
-        if (wavemask) nxt = load_quad(__builtin_ctz(wavemask));
-        while (wavemask) {  // wave-uniform
-            const int r = __builtin_ctz(wavemask);
-            wavemask &= wavemask - 1;
-            const CellQuad q = nxt;
-            if (wavemask) nxt = load_quad(__builtin_ctz(wavemask));
-            const int kz = r / 3, ky = r - 3 * kz;
-            const float rb2 = (ky == 0 ? 0.f : (ky == 1 ? by2[1] : by2[2])) + (kz == 0 ? 0.f : (kz == 1 ? bz2[1] : bz2[2]));
-            const bool pass = ((lanemask >> r) & 1u) && rb2 * 0.99999f <= B.worst();
-            if (__ballot(pass) == 0ull) continue;  // an earlier row tightened the bound
-            const unsigned c0 = has_l ? q.a : q.b, c1 = q.b, c2 = q.c, c3 = has_r ? q.d : q.c;
-            // left | own | right cells are one contiguous run: cells whose face is already
-            // within reach are scanned together with the own cell (one pass of loads instead
-            // of three dependent ones); a neighbour ruled out now stays ruled out, the bound
-            // only tightens.
-            const bool pl0 = pass && c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst();
-            const bool pr0 = pass && c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst();
-            scan_runs(B, pass, sorted, pl0 ? c0 : c1, pr0 ? c3 : c2, px, py, pz);
-        }
-        if (act && B.worst() <= C.settled_r2(G)) todo = false;
-    }
-}
 
 // Stand-alone batched search (gpscal_knn_search): one lane per query.
 template <int K>
@@ -954,20 +595,6 @@ __global__ void gather_weights_kernel(const PairDesc *__restrict__ pairs, const 
 
 // ------------------------------------------------------------- host side
 
-struct GridSet {
-    gpscal_ctx *ctx = nullptr;
-    int npairs = 0;
-    std::vector<long long> off;  // npairs + 1 point offsets
-    std::vector<PairDesc> hpairs;
-    DevBuf<PairDesc> pairs;
-    DevBuf<float4> pts4;    // caller order
-    DevBuf<float4> sorted;  // all (pair, level) blocks
-    DevBuf<float4> nbr;     // per original point: its 4 nearest other points (lazy, ICP only)
-    DevBuf<float2> pt_r2;   // per original point: (r_a^2, r_b^2) certified radii
-    DevBuf<unsigned> cell_start_buf;  // 4 pad + cells + 1 + 4 pad
-    unsigned *cell_start = nullptr;
-    long long total_cells = 0, total_sorted = 0;
-};
 
 // Chooses the level ladder for one cloud from its bounding box.
 static void plan_levels(const float mn[3], const float mx[3], int m, float cell, int max_levels, PairDesc &P)
@@ -1026,7 +653,7 @@ static void plan_levels(const float mn[3], const float mx[3], int m, float cell,
     }
 }
 
-static int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long long *off, int npairs,
+int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long long *off, int npairs,
                        float cell, int max_levels, GridSet &gs)
 {
     gs.ctx = ctx;
@@ -1135,7 +762,7 @@ static int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long 
 }
 
 // Neighbour lists and certified radii of every target point (ICP only; first use).
-static int ensure_safe_radius(gpscal_ctx *ctx, GridSet &gs)
+int ensure_safe_radius(gpscal_ctx *ctx, GridSet &gs)
 {
     if (gs.pt_r2.p) return GPSCAL_OK;
     const long long total = gs.off[gs.npairs] - gs.off[0];
@@ -1160,10 +787,6 @@ static int ensure_safe_radius(gpscal_ctx *ctx, GridSet &gs)
 
 using namespace gpscal;
 
-struct gpscal_knn_index {
-    gpscal_ctx *ctx;
-    GridSet gs;
-};
 
 struct gpscal_scan_batch {
     gpscal_ctx *ctx = nullptr;

@@ -1,0 +1,575 @@
+// loam.hip -- LOAM sweep-to-sweep scan matching (laserOdometry's Gauss-Newton loop) for
+// many independent sweeps at once: one workgroup runs ALL <= 25 iterations of one
+// sweep -- correspondences, residuals, 6x6 normal equations, solve, degeneracy
+// projection, convergence test -- with workgroup barriers only.  Sweeps of different
+// SLAM segments are independent (LOAM is reset per segment), so a launch carries one
+// sweep per segment.  gfx950 only.
+//
+// Replaces, in /root/reference/src/gpsCalibration/src/lidar_slam/loam/laserOdometry.cpp:
+//   TransformToStart / TransformToEnd      :123-150, :156-227 (IMU terms are zero under run.sh)
+//   correspondence search                  :592-677, :752-844 (kd-tree k=1 + adjacent-ring scans)
+//   point-to-line / point-to-plane terms   :680-746, :847-901
+//   Jacobian, normal equations, solve      :909-975 (cv::solve DECOMP_QR -> Householder QR, float64)
+//   degeneracy projection                  :977-1004 (cv::eigen -> cyclic Jacobi, float64)
+//   update + convergence                   :1005-1028
+//   pose accumulation                      :1035-1064
+// Points are float4 {x, y, z, intensity}; intensity = ring id + 0.1 * relative time.
+// Per-point arithmetic is float32 as in the reference; the 27 sums of the normal
+// equations are accumulated in float64 (OpenCV's float32 gemm order is not pinned).
+#include "common.hpp"
+#include "knn_device.hpp"
+#include "knn_host.hpp"
+#include "wave_reduce.hpp"
+
+#include <algorithm>
+
+namespace gpscal {
+
+constexpr int LBLOCK = 512;
+constexpr int LWAVES = LBLOCK / 64;
+constexpr int LSUMS = 28;  // 21 upper-triangle AtA + 6 AtB + 1 row count
+
+struct SweepDesc {
+    long long sharp_off, flat_off, clast_off, slast_off;  // into the packed float4 arrays
+    int nc, ns, mc, ms;
+};
+
+__device__ __forceinline__ float4 lo_to_start(const float *tr, float4 p)
+{
+    // LO:123-150
+    const float s = 10 * (p.w - (int)p.w);
+    const float rx = s * tr[0], ry = s * tr[1], rz = s * tr[2];
+    const float tx = s * tr[3], ty = s * tr[4], tz = s * tr[5];
+    const float x1 = cosf(rz) * (p.x - tx) + sinf(rz) * (p.y - ty);
+    const float y1 = -sinf(rz) * (p.x - tx) + cosf(rz) * (p.y - ty);
+    const float z1 = (p.z - tz);
+    const float x2 = x1;
+    const float y2 = cosf(rx) * y1 + sinf(rx) * z1;
+    const float z2 = -sinf(rx) * y1 + cosf(rx) * z1;
+    return make_float4(cosf(ry) * x2 - sinf(ry) * z2, y2, sinf(ry) * x2 + cosf(ry) * z2, p.w);
+}
+
+__device__ __forceinline__ float4 lo_to_end(const float *tr, float4 p)
+{
+    // LO:156-227 with the IMU stages (identities at zero IMU) left out
+    const float4 p3 = lo_to_start(tr, p);
+    const float rx = tr[0], ry = tr[1], rz = tr[2], tx = tr[3], ty = tr[4], tz = tr[5];
+    const float x4 = cosf(ry) * p3.x + sinf(ry) * p3.z;
+    const float y4 = p3.y;
+    const float z4 = -sinf(ry) * p3.x + cosf(ry) * p3.z;
+    const float x5 = x4;
+    const float y5 = cosf(rx) * y4 - sinf(rx) * z4;
+    const float z5 = sinf(rx) * y4 + cosf(rx) * z4;
+    return make_float4(cosf(rz) * x5 - sinf(rz) * y5 + tx, sinf(rz) * x5 + cosf(rz) * y5 + ty, z5 + tz,
+                       (float)(int)p.w);
+}
+
+__device__ __forceinline__ float sq3(float4 a, float4 b)
+{
+    // the plain expression of LO:627-632: products and sums, no fused multiply-add
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// One row of the linearised system (LO:916-971, s = 1): Jacobian a[6] and b = -0.05 d2.
+__device__ __forceinline__ void lo_row(const float *tr, float4 pt, float4 cf, double *sum)
+{
+    const float srx = sinf(tr[0]), crx = cosf(tr[0]), sry = sinf(tr[1]), cry = cosf(tr[1]);
+    const float srz = sinf(tr[2]), crz = cosf(tr[2]), tx = tr[3], ty = tr[4], tz = tr[5];
+    const float px = pt.x, py = pt.y, pz = pt.z, cx = cf.x, cy = cf.y, cz = cf.z;
+    float a[6];
+    a[0] = (-crx * sry * srz * px + crx * crz * sry * py + srx * sry * pz + tx * crx * sry * srz - ty * crx * crz * sry -
+            tz * srx * sry) * cx +
+           (srx * srz * px - crz * srx * py + crx * pz + ty * crz * srx - tz * crx - tx * srx * srz) * cy +
+           (crx * cry * srz * px - crx * cry * crz * py - cry * srx * pz + tz * cry * srx + ty * crx * cry * crz -
+            tx * crx * cry * srz) * cz;
+    a[1] = ((-crz * sry - cry * srx * srz) * px + (cry * crz * srx - sry * srz) * py - crx * cry * pz +
+            tx * (crz * sry + cry * srx * srz) + ty * (sry * srz - cry * crz * srx) + tz * crx * cry) * cx +
+           ((cry * crz - srx * sry * srz) * px + (cry * srz + crz * srx * sry) * py - crx * sry * pz + tz * crx * sry -
+            ty * (cry * srz + crz * srx * sry) - tx * (cry * crz - srx * sry * srz)) * cz;
+    a[2] = ((-cry * srz - crz * srx * sry) * px + (cry * crz - srx * sry * srz) * py +
+            tx * (cry * srz + crz * srx * sry) - ty * (cry * crz - srx * sry * srz)) * cx +
+           (-crx * crz * px - crx * srz * py + ty * crx * srz + tx * crx * crz) * cy +
+           ((cry * crz * srx - sry * srz) * px + (crz * sry + cry * srx * srz) * py +
+            tx * (sry * srz - cry * crz * srx) - ty * (crz * sry + cry * srx * srz)) * cz;
+    a[3] = -(cry * crz - srx * sry * srz) * cx + crx * srz * cy - (crz * sry + cry * srx * srz) * cz;
+    a[4] = -(cry * srz + crz * srx * sry) * cx - crx * crz * cy - (sry * srz - cry * crz * srx) * cz;
+    a[5] = crx * sry * cx - srx * cy - crx * cry * cz;
+    const float b = (float)(-0.05 * (double)cf.w);  // LO:970
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) sum[k++] += (double)a[r] * (double)a[c];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) sum[21 + r] += (double)a[r] * (double)b;
+    sum[27] += 1.0;
+}
+
+// ---- thread-0 dense helpers on LDS-resident 6x6 systems (float64)
+__device__ void lo_solve_qr6(double *A, double *b, double *x, double *v)
+{
+    for (int k = 0; k < 6; ++k) {
+        double nrm = 0;
+        for (int i = k; i < 6; ++i) nrm += A[6 * i + k] * A[6 * i + k];
+        nrm = sqrt(nrm);
+        if (nrm == 0.0) continue;
+        const double alpha = A[6 * k + k] > 0 ? -nrm : nrm;
+        for (int i = 0; i < 6; ++i) v[i] = i >= k ? A[6 * i + k] : 0.0;
+        v[k] -= alpha;
+        double vv = 0;
+        for (int i = k; i < 6; ++i) vv += v[i] * v[i];
+        if (vv == 0.0) continue;
+        for (int j = k; j < 6; ++j) {
+            double d = 0;
+            for (int i = k; i < 6; ++i) d += v[i] * A[6 * i + j];
+            d = 2 * d / vv;
+            for (int i = k; i < 6; ++i) A[6 * i + j] -= d * v[i];
+        }
+        double d = 0;
+        for (int i = k; i < 6; ++i) d += v[i] * b[i];
+        d = 2 * d / vv;
+        for (int i = k; i < 6; ++i) b[i] -= d * v[i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double acc = b[i];
+        for (int j = i + 1; j < 6; ++j) acc -= A[6 * i + j] * x[j];
+        x[i] = A[6 * i + i] != 0.0 ? acc / A[6 * i + i] : 0.0;
+    }
+}
+
+// eigen-decomposition of the symmetric A (destroyed); Q columns = eigenvectors
+__device__ void lo_eigen_sym6(double *A, double *Q)
+{
+    for (int i = 0; i < 36; ++i) Q[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 6; ++p)
+            for (int q = p + 1; q < 6; ++q) off += A[6 * p + q] * A[6 * p + q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 6; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                const double apq = A[6 * p + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double tau = (A[6 * q + q] - A[6 * p + p]) / (2 * apq);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1 + tau * tau));
+                const double c = 1 / sqrt(1 + t * t), s = t * c;
+                for (int k = 0; k < 6; ++k) {
+                    const double akp = A[6 * k + p], akq = A[6 * k + q];
+                    A[6 * k + p] = c * akp - s * akq;
+                    A[6 * k + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double apk = A[6 * p + k], aqk = A[6 * q + k];
+                    A[6 * p + k] = c * apk - s * aqk;
+                    A[6 * q + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double qkp = Q[6 * k + p], qkq = Q[6 * k + q];
+                    Q[6 * k + p] = c * qkp - s * qkq;
+                    Q[6 * k + q] = s * qkp + c * qkq;
+                }
+            }
+    }
+}
+
+// Exact 1-NN of p in one indexed cloud (pair b of a GridSet); all lanes of the wave call it.
+__device__ __forceinline__ void lo_nearest(const PairDesc &P, const float4 *__restrict__ sorted,
+                                           const unsigned *__restrict__ cell_start, bool act, float4 p, int &idx,
+                                           float &sqd)
+{
+    Best<1> B;
+    B.init();
+    knn_query(P, sorted, cell_start, act, p.x, p.y, p.z, B);
+    idx = B.i[0] == 0x7fffffff ? -1 : B.i[0];
+    sqd = B.d[0];
+}
+
+__global__ __launch_bounds__(LBLOCK) void loam_odometry_kernel(
+    const SweepDesc *__restrict__ sweeps, const float4 *__restrict__ sharp, const float4 *__restrict__ flat,
+    const float4 *__restrict__ clast, const float4 *__restrict__ slast, const PairDesc *__restrict__ cpairs,
+    const float4 *__restrict__ csorted, const unsigned *__restrict__ ccells, const PairDesc *__restrict__ spairs,
+    const float4 *__restrict__ ssorted, const unsigned *__restrict__ scells, int *__restrict__ corr,
+    const float *__restrict__ tr_in, float *__restrict__ tr_out, int *__restrict__ iters_out,
+    int *__restrict__ nsel_out, const float *__restrict__ sum_in, float *__restrict__ sum_out)
+{
+    __shared__ float tr[6];
+    __shared__ double red[LWAVES][LSUMS];
+    __shared__ double sA[36], sB[6], sX[6], sV[6], sQ[36], sP[36], sE[36];
+    __shared__ int s_flags[3];  // degenerate, done, last nsel
+    const int b = blockIdx.x;
+    const SweepDesc D = sweeps[b];
+    const PairDesc &CP = cpairs[b];
+    const PairDesc &SP = spairs[b];
+    const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off, *cl = clast + D.clast_off,
+                 *sl = slast + D.slast_off;
+    // correspondence indices of this sweep: ci1, ci2 | si1, si2, si3
+    int *ci1 = corr + 2 * D.sharp_off + 3 * D.flat_off, *ci2 = ci1 + D.nc;
+    int *si1 = ci2 + D.nc, *si2 = si1 + D.ns, *si3 = si2 + D.ns;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 6) tr[threadIdx.x] = tr_in[6 * b + threadIdx.x];
+    if (threadIdx.x < 36) sP[threadIdx.x] = (threadIdx.x % 7 == 0) ? 1.0 : 0.0;
+    if (threadIdx.x == 0) {
+        s_flags[0] = 0;
+        s_flags[1] = 0;
+        s_flags[2] = 0;
+    }
+    for (int i = threadIdx.x; i < D.nc; i += LBLOCK) ci1[i] = ci2[i] = -1;
+    for (int i = threadIdx.x; i < D.ns; i += LBLOCK) si1[i] = si2[i] = si3[i] = -1;
+    __syncthreads();
+    int iters = 0;
+    const bool enough = D.mc > 10 && D.ms > 100;  // LO:569
+    // forward ring scans are bounded by the CURRENT sweep's feature counts (LO:620,776)
+    const int fwd_c = min(D.nc, D.mc), fwd_s = min(D.ns, D.ms);
+
+    for (int it = 0; enough && it < 25; ++it) {  // LO:585
+        ++iters;
+        double sum[LSUMS];
+#pragma unroll
+        for (int k = 0; k < LSUMS; ++k) sum[k] = 0.0;
+        const bool search = it % 5 == 0;
+
+        // ---- corner features: point-to-line (LO:592-746)
+        for (int i0 = 0; i0 < D.nc; i0 += LBLOCK) {
+            const int i = i0 + threadIdx.x;
+            const bool act = i < D.nc;
+            float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act) pi = sh[i];
+            const float4 ps = lo_to_start(tr, pi);
+            if (search) {  // uniform
+                int idx;
+                float sqd;
+                lo_nearest(CP, csorted, ccells, act, ps, idx, sqd);
+                int closest = -1, min2 = -1;
+                if (act && idx >= 0 && sqd < 25) {
+                    closest = idx;
+                    const int scan = (int)cl[closest].w;
+                    float d2min = 25;
+                    for (int j = closest + 1; j < fwd_c; ++j) {
+                        const float4 q = cl[j];
+                        if ((int)q.w > scan + 1.5) break;
+                        const float d = sq3(q, ps);
+                        if ((int)q.w > scan && d < d2min) {
+                            d2min = d;
+                            min2 = j;
+                        }
+                    }
+                    for (int j = closest - 1; j >= 0; --j) {
+                        const float4 q = cl[j];
+                        if ((int)q.w < scan - 1.5) break;
+                        const float d = sq3(q, ps);
+                        if ((int)q.w < scan && d < d2min) {
+                            d2min = d;
+                            min2 = j;
+                        }
+                    }
+                }
+                if (act) {
+                    ci1[i] = closest;
+                    ci2[i] = min2;
+                }
+            }
+            if (act && ci2[i] >= 0) {
+                const float4 t1 = cl[ci1[i]], t2 = cl[ci2[i]];
+                const float x0 = ps.x, y0 = ps.y, z0 = ps.z;
+                const float x1 = t1.x, y1 = t1.y, z1 = t1.z, x2 = t2.x, y2 = t2.y, z2 = t2.z;
+                const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
+                const float m22 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
+                const float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
+                const float a012 = sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
+                const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+                const float la = ((y1 - y2) * m11 + (z1 - z2) * m22) / a012 / l12;
+                const float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) / a012 / l12;
+                const float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) / a012 / l12;
+                const float ld2 = a012 / l12;
+                float s = 1;
+                if (it >= 5) s = (float)(1 - 1.8 * fabs((double)ld2));
+                if (s > 0.1 && ld2 != 0) lo_row(tr, pi, make_float4(s * la, s * lb, s * lc, s * ld2), sum);
+            }
+        }
+        // ---- surface features: point-to-plane (LO:752-901)
+        for (int i0 = 0; i0 < D.ns; i0 += LBLOCK) {
+            const int i = i0 + threadIdx.x;
+            const bool act = i < D.ns;
+            float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act) pi = fl[i];
+            const float4 ps = lo_to_start(tr, pi);
+            if (search) {
+                int idx;
+                float sqd;
+                lo_nearest(SP, ssorted, scells, act, ps, idx, sqd);
+                int closest = -1, min2 = -1, min3 = -1;
+                if (act && idx >= 0 && sqd < 25) {
+                    closest = idx;
+                    const int scan = (int)sl[closest].w;
+                    float d2 = 25, d3 = 25;
+                    for (int j = closest + 1; j < fwd_s; ++j) {
+                        const float4 q = sl[j];
+                        if ((int)q.w > scan + 1.5) break;
+                        const float d = sq3(q, ps);
+                        if ((int)q.w <= scan) {
+                            if (d < d2) { d2 = d; min2 = j; }
+                        } else {
+                            if (d < d3) { d3 = d; min3 = j; }
+                        }
+                    }
+                    for (int j = closest - 1; j >= 0; --j) {
+                        const float4 q = sl[j];
+                        if ((int)q.w < scan - 1.5) break;
+                        const float d = sq3(q, ps);
+                        if ((int)q.w >= scan) {
+                            if (d < d2) { d2 = d; min2 = j; }
+                        } else {
+                            if (d < d3) { d3 = d; min3 = j; }
+                        }
+                    }
+                }
+                if (act) {
+                    si1[i] = closest;
+                    si2[i] = min2;
+                    si3[i] = min3;
+                }
+            }
+            if (act && si2[i] >= 0 && si3[i] >= 0) {
+                const float4 t1 = sl[si1[i]], t2 = sl[si2[i]], t3 = sl[si3[i]];
+                float pa = (t2.y - t1.y) * (t3.z - t1.z) - (t3.y - t1.y) * (t2.z - t1.z);
+                float pb = (t2.z - t1.z) * (t3.x - t1.x) - (t3.z - t1.z) * (t2.x - t1.x);
+                float pc = (t2.x - t1.x) * (t3.y - t1.y) - (t3.x - t1.x) * (t2.y - t1.y);
+                float pd = -(pa * t1.x + pb * t1.y + pc * t1.z);
+                const float pn = sqrtf(pa * pa + pb * pb + pc * pc);
+                pa /= pn; pb /= pn; pc /= pn; pd /= pn;
+                const float pd2 = pa * ps.x + pb * ps.y + pc * ps.z + pd;
+                float s = 1;
+                if (it >= 5)
+                    s = (float)(1 - 1.8 * fabs((double)pd2) / (double)sqrtf(sqrtf(ps.x * ps.x + ps.y * ps.y + ps.z * ps.z)));
+                if (s > 0.1 && pd2 != 0) lo_row(tr, pi, make_float4(s * pa, s * pb, s * pc, s * pd2), sum);
+            }
+        }
+        // ---- block reduction of the 28 sums (fixed order)
+#pragma unroll
+        for (int k = 0; k < LSUMS; ++k) {
+            const double v = wave_sum(sum[k]);
+            if (lane == 0) red[wave][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot[LSUMS];
+            for (int k = 0; k < LSUMS; ++k) {
+                double v = 0;
+                for (int w = 0; w < LWAVES; ++w) v += red[w][k];
+                tot[k] = v;
+            }
+            const int nsel = (int)tot[27];
+            s_flags[2] = nsel;
+            if (nsel >= 10) {  // LO:905-907
+                int k = 0;
+                for (int r = 0; r < 6; ++r)
+                    for (int c = r; c < 6; ++c) {
+                        sA[6 * r + c] = tot[k];
+                        sA[6 * c + r] = tot[k];
+                        ++k;
+                    }
+                for (int r = 0; r < 6; ++r) sB[r] = tot[21 + r];
+                if (it == 0) {  // LO:977-997: eigenvalues below 10 mark degenerate directions
+                    for (int i = 0; i < 36; ++i) sE[i] = sA[i];
+                    lo_eigen_sym6(sE, sQ);
+                    // P = V^-1 V2 with rows of V = eigenvectors: P = sum over kept eigenvectors q q^T
+                    // "kept" = all but the trailing run of eigenvalues < 10 in descending order
+                    double ev[6];
+                    int order[6];
+                    for (int i = 0; i < 6; ++i) {
+                        ev[i] = sE[7 * i];
+                        order[i] = i;
+                    }
+                    for (int i = 0; i < 6; ++i)
+                        for (int j = i + 1; j < 6; ++j)
+                            if (ev[order[j]] > ev[order[i]]) {
+                                const int t = order[i];
+                                order[i] = order[j];
+                                order[j] = t;
+                            }
+                    int keep = 6;
+                    while (keep > 0 && ev[order[keep - 1]] < 10.0) --keep;
+                    s_flags[0] = keep < 6;
+                    for (int r = 0; r < 6; ++r)
+                        for (int c = 0; c < 6; ++c) {
+                            double acc = 0;
+                            for (int k2 = 0; k2 < keep; ++k2) acc += sQ[6 * r + order[k2]] * sQ[6 * c + order[k2]];
+                            sP[6 * r + c] = acc;
+                        }
+                }
+                lo_solve_qr6(sA, sB, sX, sV);  // LO:975
+                if (s_flags[0]) {              // LO:999-1003
+                    double x2[6];
+                    for (int r = 0; r < 6; ++r) {
+                        double acc = 0;
+                        for (int c = 0; c < 6; ++c) acc += sP[6 * r + c] * sX[c];
+                        x2[r] = acc;
+                    }
+                    for (int r = 0; r < 6; ++r) sX[r] = x2[r];
+                }
+                float xf[6];
+                for (int k2 = 0; k2 < 6; ++k2) {
+                    xf[k2] = (float)sX[k2];
+                    float v = tr[k2] + xf[k2];
+                    if (isnan(v)) v = 0;  // LO:1012-1015
+                    tr[k2] = v;
+                }
+                const double r2d = 180.0 / 3.14159265358979323846;
+                const float dR = (float)sqrt((xf[0] * r2d) * (xf[0] * r2d) + (xf[1] * r2d) * (xf[1] * r2d) +
+                                             (xf[2] * r2d) * (xf[2] * r2d));
+                const float dT = (float)sqrt(((double)xf[3] * 100) * ((double)xf[3] * 100) +
+                                             ((double)xf[4] * 100) * ((double)xf[4] * 100) +
+                                             ((double)xf[5] * 100) * ((double)xf[5] * 100));
+                if (dR < 0.1 && dT < 0.1) s_flags[1] = 1;  // LO:1026
+            }
+        }
+        __syncthreads();
+        if (s_flags[1]) break;
+    }
+    if (threadIdx.x < 6) tr_out[6 * b + threadIdx.x] = tr[threadIdx.x];
+    if (threadIdx.x == 0) {
+        if (iters_out) iters_out[b] = iters;
+        if (nsel_out) nsel_out[b] = s_flags[2];
+        if (sum_in && sum_out) {
+            // pose accumulation, LO:1035-1064 with zero IMU terms
+            const float *S = sum_in + 6 * b;
+            const float cx = S[0], cy = S[1], cz = S[2];
+            const float lx = -tr[0], ly = (float)(-tr[1] * 1.05), lz = -tr[2];
+            const float srx = cosf(lx) * cosf(cx) * sinf(ly) * sinf(cz) - cosf(cx) * cosf(cz) * sinf(lx) -
+                              cosf(lx) * cosf(ly) * sinf(cx);
+            const float ox = -asinf(srx);
+            const float srycrx = sinf(lx) * (cosf(cy) * sinf(cz) - cosf(cz) * sinf(cx) * sinf(cy)) +
+                                 cosf(lx) * sinf(ly) * (cosf(cy) * cosf(cz) + sinf(cx) * sinf(cy) * sinf(cz)) +
+                                 cosf(lx) * cosf(ly) * cosf(cx) * sinf(cy);
+            const float crycrx = cosf(lx) * cosf(ly) * cosf(cx) * cosf(cy) -
+                                 cosf(lx) * sinf(ly) * (cosf(cz) * sinf(cy) - cosf(cy) * sinf(cx) * sinf(cz)) -
+                                 sinf(lx) * (sinf(cy) * sinf(cz) + cosf(cy) * cosf(cz) * sinf(cx));
+            const float oy = atan2f(srycrx / cosf(ox), crycrx / cosf(ox));
+            const float srzcrx = sinf(cx) * (cosf(lz) * sinf(ly) - cosf(ly) * sinf(lx) * sinf(lz)) +
+                                 cosf(cx) * sinf(cz) * (cosf(ly) * cosf(lz) + sinf(lx) * sinf(ly) * sinf(lz)) +
+                                 cosf(lx) * cosf(cx) * cosf(cz) * sinf(lz);
+            const float crzcrx = cosf(lx) * cosf(lz) * cosf(cx) * cosf(cz) -
+                                 cosf(cx) * sinf(cz) * (cosf(ly) * sinf(lz) - cosf(lz) * sinf(lx) * sinf(ly)) -
+                                 sinf(cx) * (sinf(ly) * sinf(lz) + cosf(ly) * cosf(lz) * sinf(lx));
+            const float oz = atan2f(srzcrx / cosf(ox), crzcrx / cosf(ox));
+            const float rx = ox, ry = oy, rz = oz;
+            const float x1 = cosf(rz) * tr[3] - sinf(rz) * tr[4];
+            const float y1 = sinf(rz) * tr[3] + cosf(rz) * tr[4];
+            const float z1 = (float)(tr[5] * 1.05);
+            const float x2 = x1;
+            const float y2 = cosf(rx) * y1 - sinf(rx) * z1;
+            const float z2 = sinf(rx) * y1 + cosf(rx) * z1;
+            float *O = sum_out + 6 * b;
+            const float acx = -asinf(-sinf(rx));
+            O[0] = acx;
+            O[1] = atan2f(cosf(rx) * sinf(ry) / cosf(acx), cosf(rx) * cosf(ry) / cosf(acx));
+            O[2] = atan2f(cosf(rx) * sinf(rz) / cosf(acx), cosf(rx) * cosf(rz) / cosf(acx));
+            O[3] = S[3] - (cosf(ry) * x2 + sinf(ry) * z2);
+            O[4] = S[4] - y2;
+            O[5] = S[5] - (-sinf(ry) * x2 + cosf(ry) * z2);
+        }
+    }
+}
+
+__global__ void loam_to_end_kernel(const float *__restrict__ tr6, const float4 *__restrict__ in, int n,
+                                   float4 *__restrict__ out, int to_end)
+{
+    __shared__ float tr[6];
+    if (threadIdx.x < 6) tr[threadIdx.x] = tr6[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = to_end ? lo_to_end(tr, in[i]) : lo_to_start(tr, in[i]);
+}
+
+}  // namespace gpscal
+
+using namespace gpscal;
+
+extern "C" int gpscal_loam_odometry_batched(gpscal_ctx *ctx, int nsweeps, const float *sharp_xyzi,
+                                            const int *sharp_off, const float *flat_xyzi, const int *flat_off,
+                                            const float *corner_last_xyzi, const int *corner_last_off,
+                                            const float *surf_last_xyzi, const int *surf_last_off,
+                                            const float *transform_in, float *transform_out, int *iters_out,
+                                            int *nsel_out, const float *transform_sum_in, float *transform_sum_out)
+{
+    if (!ctx || nsweeps < 1 || !sharp_xyzi || !sharp_off || !flat_xyzi || !flat_off || !corner_last_xyzi ||
+        !corner_last_off || !surf_last_xyzi || !surf_last_off || !transform_in || !transform_out)
+        return fail(ctx, GPSCAL_EINVAL, "gpscal_loam_odometry_batched: bad argument");
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    const int tc = sharp_off[nsweeps], tf = flat_off[nsweeps], tcl = corner_last_off[nsweeps],
+              tsl = surf_last_off[nsweeps];
+    std::vector<SweepDesc> hs(nsweeps);
+    std::vector<long long> coff(nsweeps + 1), soff(nsweeps + 1);
+    for (int b = 0; b <= nsweeps; ++b) {
+        coff[b] = corner_last_off[b];
+        soff[b] = surf_last_off[b];
+    }
+    for (int b = 0; b < nsweeps; ++b) {
+        SweepDesc &D = hs[b];
+        D.sharp_off = sharp_off[b];
+        D.flat_off = flat_off[b];
+        D.clast_off = corner_last_off[b];
+        D.slast_off = surf_last_off[b];
+        D.nc = sharp_off[b + 1] - sharp_off[b];
+        D.ns = flat_off[b + 1] - flat_off[b];
+        D.mc = corner_last_off[b + 1] - corner_last_off[b];
+        D.ms = surf_last_off[b + 1] - surf_last_off[b];
+        if (D.nc < 0 || D.ns < 0 || D.mc < 0 || D.ms < 0) return fail(ctx, GPSCAL_EINVAL, "bad offsets");
+    }
+    InArg<float> a_sh, a_fl, a_cl, a_sl, a_tr, a_sum;
+    OutArg<float> o_tr, o_sum;
+    OutArg<int> o_it, o_ns;
+    GPSCAL_HIP(ctx, a_sh.bind(ctx, sharp_xyzi, (size_t)std::max(tc, 1) * 4));
+    GPSCAL_HIP(ctx, a_fl.bind(ctx, flat_xyzi, (size_t)std::max(tf, 1) * 4));
+    GPSCAL_HIP(ctx, a_cl.bind(ctx, corner_last_xyzi, (size_t)std::max(tcl, 1) * 4));
+    GPSCAL_HIP(ctx, a_sl.bind(ctx, surf_last_xyzi, (size_t)std::max(tsl, 1) * 4));
+    GPSCAL_HIP(ctx, a_tr.bind(ctx, transform_in, (size_t)nsweeps * 6));
+    GPSCAL_HIP(ctx, a_sum.bind(ctx, transform_sum_in, transform_sum_in ? (size_t)nsweeps * 6 : 0));
+    GPSCAL_HIP(ctx, o_tr.bind(ctx, transform_out, (size_t)nsweeps * 6));
+    GPSCAL_HIP(ctx, o_sum.bind(ctx, transform_sum_out, transform_sum_out ? (size_t)nsweeps * 6 : 0));
+    GPSCAL_HIP(ctx, o_it.bind(ctx, iters_out, iters_out ? nsweeps : 0));
+    GPSCAL_HIP(ctx, o_ns.bind(ctx, nsel_out, nsel_out ? nsweeps : 0));
+    // the kd-trees of the last sweep (setInputCloud, LO:538-539,1119-1120) = two grid sets
+    GridSet cg, sg;
+    int rc = build_grids(ctx, a_cl.dev, 16, coff.data(), nsweeps, 0.f, MAX_LEVELS, cg);
+    if (!rc) rc = build_grids(ctx, a_sl.dev, 16, soff.data(), nsweeps, 0.f, MAX_LEVELS, sg);
+    if (rc) return rc;
+    DevBuf<SweepDesc> d_sw;
+    DevBuf<int> corr;
+    GPSCAL_HIP(ctx, d_sw.alloc_async(nsweeps, ctx->stream));
+    GPSCAL_HIP(ctx, corr.alloc_async((size_t)2 * tc + (size_t)3 * tf + 8, ctx->stream));
+    GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, hs.data(), sizeof(SweepDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(loam_odometry_kernel, dim3(nsweeps), dim3(LBLOCK), 0, ctx->stream, d_sw.p,
+                       reinterpret_cast<const float4 *>(a_sh.dev), reinterpret_cast<const float4 *>(a_fl.dev),
+                       reinterpret_cast<const float4 *>(a_cl.dev), reinterpret_cast<const float4 *>(a_sl.dev),
+                       cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p, sg.cell_start, corr.p,
+                       a_tr.dev, o_tr.dev, o_it.dev, o_ns.dev, a_sum.dev, o_sum.dev);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    bool sync = true;
+    GPSCAL_HIP(ctx, o_tr.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, o_sum.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, o_it.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, o_ns.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}
+
+extern "C" int gpscal_loam_transform(gpscal_ctx *ctx, const float *tr6, const float *pts_xyzi, int n, float *out_xyzi,
+                                     int to_end)
+{
+    if (!ctx || !tr6 || !pts_xyzi || !out_xyzi || n < 1) return fail(ctx, GPSCAL_EINVAL, "gpscal_loam_transform: bad argument");
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    InArg<float> t, p;
+    OutArg<float> o;
+    GPSCAL_HIP(ctx, t.bind(ctx, tr6, 6));
+    GPSCAL_HIP(ctx, p.bind(ctx, pts_xyzi, (size_t)n * 4));
+    GPSCAL_HIP(ctx, o.bind(ctx, out_xyzi, (size_t)n * 4));
+    hipLaunchKernelGGL(loam_to_end_kernel, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, t.dev,
+                       reinterpret_cast<const float4 *>(p.dev), n, reinterpret_cast<float4 *>(o.dev), to_end);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    bool sync = true;
+    GPSCAL_HIP(ctx, o.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}

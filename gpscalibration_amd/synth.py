@@ -216,3 +216,82 @@ def write_track_file(path, longs, shorts):
                 f.write("%d %d\n" % (flag, len(s)))
                 for r in s:
                     f.write("%.17g %.17g %.17g %.17g\n" % tuple(r))
+
+
+# ------------------------------------------------------------ LOAM feature sweeps
+def _small_rot(r):
+    """LOAM's rotation order of TransformToStart's inverse: Rz(rz) Rx(rx) Ry(ry) on (x,y,z)."""
+    rx, ry, rz = r
+    cz, sz, cx, sx, cy, sy = math.cos(rz), math.sin(rz), math.cos(rx), math.sin(rx), math.cos(ry), math.sin(ry)
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    return Rz @ Rx @ Ry
+
+
+def loam_sweep(motion, seed=0, n_az=900, sensor_h=1.8):
+    """One VLP-16-like sweep of a box room with poles, as LOAM feature clouds.
+
+    `motion` = (rx,ry,rz,tx,ty,tz) of the sensor over the sweep (start frame -> end frame, constant
+    rate).  A point captured at relative time s is seen from the pose s*motion.  Returns
+    dict(sharp, less_sharp, flat, less_flat) of float32 [n,4] {x,y,z,intensity} in the frame of
+    capture; intensity = ring + 0.1*s (scanRegistration.cpp:340-362); clouds are ordered by ring,
+    then azimuth.  Axes: LOAM's (y up): ground is the plane y = -sensor_h.
+    """
+    rng = np.random.default_rng(seed)
+    motion = np.asarray(motion, dtype=np.float64)
+    elev = np.radians(np.linspace(-15, 15, 16))
+    az = np.linspace(-math.pi, math.pi, n_az, endpoint=False)
+    poles = np.array([[6, 4], [-7, 5], [9, -6], [-5, -8], [12, 9], [-11, -3], [3, -11], [-2, 12]], dtype=np.float64)
+    half = np.array([20.0, 15.0])  # room half sizes in (z, x)
+    out = {"sharp": [], "less_sharp": [], "flat": [], "less_flat": []}
+    for ring in range(16):
+        ce, se = math.cos(elev[ring]), math.sin(elev[ring])
+        pts, kind = [], []
+        for k in range(n_az):
+            s = k / n_az
+            R = _small_rot(s * motion[:3])
+            t = s * motion[3:]
+            d_s = np.array([ce * math.sin(az[k]), se, ce * math.cos(az[k])])  # sensor frame (x left, y up, z fwd)
+            d = R @ d_s
+            o = t.copy()
+            best, bk = 1e9, -1
+            if d[1] < -1e-6:  # ground y = -h
+                lam = (-sensor_h - o[1]) / d[1]
+                if 0 < lam < best:
+                    best, bk = lam, 0
+            for axis, sign in ((2, 1), (2, -1), (0, 1), (0, -1)):  # walls z = +-20, x = +-15
+                lim = half[0] if axis == 2 else half[1]
+                if abs(d[axis]) > 1e-9:
+                    lam = (sign * lim - o[axis]) / d[axis]
+                    if 0 < lam < best:
+                        best, bk = lam, 1
+            for pc in poles:  # vertical cylinders r = 0.15 at (z, x) = pc
+                oz, ox = o[2] - pc[0], o[0] - pc[1]
+                a = d[2] * d[2] + d[0] * d[0]
+                b = 2 * (oz * d[2] + ox * d[0])
+                c = oz * oz + ox * ox - 0.15 * 0.15
+                disc = b * b - 4 * a * c
+                if disc > 0 and a > 1e-12:
+                    lam = (-b - math.sqrt(disc)) / (2 * a)
+                    if 0 < lam < best:
+                        best, bk = lam, 2
+            if bk < 0:
+                continue
+            pw = o + best * d + rng.normal(0, 0.005, 3)
+            ps = R.T @ (pw - t)  # back into the frame of capture
+            pts.append([ps[0], ps[1], ps[2], ring + 0.1 * s])
+            kind.append(bk)
+        pts = np.array(pts, dtype=np.float32)
+        kind = np.array(kind)
+        pole_idx = np.flatnonzero(kind == 2)
+        plane_idx = np.flatnonzero(kind != 2)
+        # runs of consecutive pole hits: middle sample = sharp, all = less sharp
+        if len(pole_idx):
+            runs = np.split(pole_idx, np.flatnonzero(np.diff(pole_idx) > 1) + 1)
+            for r_ in runs:
+                out["sharp"].append(pts[r_[len(r_) // 2]][None])
+                out["less_sharp"].append(pts[r_])
+        out["flat"].append(pts[plane_idx[::12]])
+        out["less_flat"].append(pts[plane_idx[::3]])
+    return {k: np.concatenate(v).astype(np.float32) for k, v in out.items()}

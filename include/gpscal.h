@@ -209,6 +209,34 @@ int gpscal_icp_run(gpscal_ctx *ctx, gpscal_knn_index *index,
                    const double *w, int iters, const double *T0, double *T_out,
                    double *mean_err_hist);
 
+/* ------------------------------------------------------- LOAM odometry */
+/* Replaces the per-sweep Gauss-Newton loop of laserOdometry (LO:585-1029) for nsweeps
+ * INDEPENDENT sweeps (one per SLAM segment; LOAM is reset per segment, LO:519-563) in one
+ * launch: TransformToStart (LO:123-150), kd-tree k=1 + adjacent-ring correspondence search
+ * every 5th iteration (LO:592-677, 752-844), point-to-line / point-to-plane terms
+ * (LO:680-746, 847-901), 6x6 normal equations + QR solve (LO:909-975), degeneracy
+ * projection at iteration 0 (LO:977-1004), update and the 0.1 deg / 0.1 cm stop (LO:1005-1028).
+ * Points are float[4] {x, y, z, intensity}, intensity = ring id + 0.1 * relative time
+ * (scanRegistration.cpp:340-362), clouds ordered by ring as scanRegistration emits them;
+ * *_off are nsweeps+1 point offsets.  sharp / flat = cornerPointsSharp / surfPointsFlat of the
+ * current sweep, corner_last / surf_last = laserCloudCornerLast / laserCloudSurfLast.
+ * transform_* are LOAM's float[6] {rx, ry, rz, tx, ty, tz} per sweep.  Optional:
+ * iters_out, nsel_out (rows of the last linear system), transform_sum_in/out = pose
+ * accumulation (LO:1035-1064).  The IMU terms are zero (nothing publishes /imu/data under
+ * run.sh, input_data.cpp:259-262). */
+int gpscal_loam_odometry_batched(gpscal_ctx *ctx, int nsweeps,
+                                 const float *sharp_xyzi, const int *sharp_off,
+                                 const float *flat_xyzi, const int *flat_off,
+                                 const float *corner_last_xyzi, const int *corner_last_off,
+                                 const float *surf_last_xyzi, const int *surf_last_off,
+                                 const float *transform_in, float *transform_out,
+                                 int *iters_out, int *nsel_out,
+                                 const float *transform_sum_in, float *transform_sum_out);
+/* TransformToStart (to_end = 0, LO:123-150) / TransformToEnd (to_end = 1, LO:156-227)
+ * of n points with one transform. */
+int gpscal_loam_transform(gpscal_ctx *ctx, const float *transform6,
+                          const float *pts_xyzi, int n, float *out_xyzi, int to_end);
+
 /* ------------------------------------------------------------- multi-GPU */
 /* New (no reference counterpart): the one exchange of the sharded pipeline,
  * an RCCL all-gather of per-segment pose chains / fit results over xGMI

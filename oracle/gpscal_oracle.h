@@ -149,6 +149,18 @@ int orc_icp_run(const orc_kdtree *t, const float *src, int n, const double *w,
 void orc_transform_f32(const double T[16], const float *src, int n,
                        float *dst);
 
+/* ----------------------------------------------------- LOAM odometry (LO) */
+/* Points are float[4] {x,y,z,intensity}; transforms are LOAM's float[6]
+ * {rx,ry,rz,tx,ty,tz}.  laserOdometry.cpp:123-150 / 156-227 (IMU terms zero). */
+void orc_lo_transform_to_start(const float tr[6], const float *pi, float *po);
+void orc_lo_transform_to_end(const float tr[6], const float *pi, float *po);
+/* The Gauss-Newton loop of one sweep (laserOdometry.cpp:585-1029). */
+int orc_lo_match(const float *sharp, int nc, const float *flat, int ns, const float *cornerLast, int mc,
+                 const float *surfLast, int ms, const float tr_in[6], float tr_out[6], int *iters_out,
+                 int *nsel_out);
+/* Pose accumulation (laserOdometry.cpp:1035-1064, IMU terms zero). */
+void orc_lo_accumulate(const float sum_in[6], const float tr[6], float sum_out[6]);
+
 #ifdef __cplusplus
 }
 #endif

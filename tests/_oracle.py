@@ -265,3 +265,32 @@ def transform_f32(T, src):
     dst = np.empty_like(src)
     lib().orc_transform_f32(_p(T, c_dp), _p(src, c_fp), len(src), _p(dst, c_fp))
     return dst
+
+
+# --------------------------------------------------------------------- LOAM
+def lo_transform(tr, pts, to_end=False):
+    tr = np.ascontiguousarray(tr, dtype=np.float32)
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    out = np.empty_like(pts)
+    fn = lib().orc_lo_transform_to_end if to_end else lib().orc_lo_transform_to_start
+    for i in range(len(pts)):
+        fn(_p(tr, c_fp), C.c_void_p(pts.ctypes.data + 16 * i), C.c_void_p(out.ctypes.data + 16 * i))
+    return out
+
+
+def lo_match(sharp, flat, corner_last, surf_last, tr_in=None):
+    a = [np.ascontiguousarray(x, dtype=np.float32) for x in (sharp, flat, corner_last, surf_last)]
+    tr_in = np.zeros(6, dtype=np.float32) if tr_in is None else np.ascontiguousarray(tr_in, dtype=np.float32)
+    tr = np.empty(6, dtype=np.float32)
+    it, ns = C.c_int(0), C.c_int(0)
+    lib().orc_lo_match(_p(a[0], c_fp), len(a[0]), _p(a[1], c_fp), len(a[1]), _p(a[2], c_fp), len(a[2]),
+                       _p(a[3], c_fp), len(a[3]), _p(tr_in, c_fp), _p(tr, c_fp), C.byref(it), C.byref(ns))
+    return tr, it.value, ns.value
+
+
+def lo_accumulate(sum_in, tr):
+    s = np.ascontiguousarray(sum_in, dtype=np.float32)
+    t = np.ascontiguousarray(tr, dtype=np.float32)
+    out = np.empty(6, dtype=np.float32)
+    lib().orc_lo_accumulate(_p(s, c_fp), _p(t, c_fp), _p(out, c_fp))
+    return out
