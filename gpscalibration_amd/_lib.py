@@ -16,7 +16,7 @@ EXPORTS = [
     "gpscal_scan_batch_create", "gpscal_scan_batch_set_pose", "gpscal_scan_batch_icp",
     "gpscal_scan_batch_correspondences", "gpscal_scan_batch_build_seconds", "gpscal_scan_batch_destroy",
     "gpscal_icp_iterate", "gpscal_icp_run",
-    "gpscal_loam_odometry_batched", "gpscal_loam_transform",
+    "gpscal_loam_odometry_batched", "gpscal_loam_mapping_batched", "gpscal_loam_transform",
     "gpscal_comm_unique_id", "gpscal_comm_init", "gpscal_allgather_chains", "gpscal_comm_destroy",
 ]
 
@@ -91,6 +91,7 @@ def load():
     L.gpscal_icp_iterate.argtypes = [vp, vp, fp, i, i, dp, dp, dp, dp]
     L.gpscal_icp_run.argtypes = [vp, vp, fp, i, i, dp, i, dp, dp, dp]
     L.gpscal_loam_odometry_batched.argtypes = [vp, i, fp, ip, fp, ip, fp, ip, fp, ip, fp, fp, ip, ip, fp, fp]
+    L.gpscal_loam_mapping_batched.argtypes = [vp, i, fp, ip, fp, ip, fp, ip, fp, ip, fp, fp, ip, ip]
     L.gpscal_loam_transform.argtypes = [vp, fp, fp, i, fp, i]
     L.gpscal_comm_unique_id.argtypes = [vp]
     L.gpscal_comm_init.argtypes = [vp, vp, i, i]

@@ -197,6 +197,29 @@ class Context:
                                                       _ptr(nsel), _ptr(sin), _ptr(sout)), "loam_odometry_batched")
         return tout, iters, nsel, sout
 
+    def loam_mapping(self, corner_stack, surf_stack, corner_map, surf_map, transform_in=None):
+        """Batched laserMapping optimisation loop (laserMapping.cpp:748-1018).  Each cloud argument is a
+        list of [n,4] float32 arrays (one per sweep).  Returns (transformTobeMapped[nsweeps,6], iters, nsel)."""
+        ns = len(corner_stack)
+
+        def pack(lst):
+            off = np.zeros(ns + 1, dtype=np.int32)
+            off[1:] = np.cumsum([len(a) for a in lst])
+            data = np.ascontiguousarray(np.concatenate(lst) if off[-1] else np.zeros((1, 4)), dtype=np.float32)
+            return data, off
+        cs, cso = pack(corner_stack)
+        ss, sso = pack(surf_stack)
+        cm, cmo = pack(corner_map)
+        sm, smo = pack(surf_map)
+        tin = np.zeros((ns, 6), dtype=np.float32) if transform_in is None else np.ascontiguousarray(transform_in, dtype=np.float32)
+        tout = np.empty((ns, 6), dtype=np.float32)
+        iters = np.empty(ns, dtype=np.int32)
+        nsel = np.empty(ns, dtype=np.int32)
+        self._ck(self._L.gpscal_loam_mapping_batched(self._h, ns, _ptr(cs), _ptr(cso), _ptr(ss), _ptr(sso), _ptr(cm),
+                                                     _ptr(cmo), _ptr(sm), _ptr(smo), _ptr(tin), _ptr(tout), _ptr(iters),
+                                                     _ptr(nsel)), "loam_mapping_batched")
+        return tout, iters, nsel
+
     def loam_transform(self, transform6, pts_xyzi, to_end=False):
         t = np.ascontiguousarray(transform6, dtype=np.float32)
         p = np.ascontiguousarray(pts_xyzi, dtype=np.float32)

@@ -472,6 +472,378 @@ __global__ __launch_bounds__(LBLOCK) void loam_odometry_kernel(
     }
 }
 
+// ===================================================================================
+// laserMapping's sweep-to-map optimisation (laserMapping.cpp:748-1018): <= 10 iterations,
+// every one with a fresh k=5 search of each stacked feature in the local map.
+//   pointAssociateToMap                     LM:244-262
+//   corner: 5-NN covariance, cv::eigen, line LM:757-858 (cyclic Jacobi 3x3, float64)
+//   surf: 5-NN plane fit cv::solve QR        LM:860-920 (Householder 5x3, float64)
+//   Jacobian / normal equations / solve      LM:922-968
+//   degeneracy (eigenvalues < 100), update   LM:970-1018
+// ===================================================================================
+
+// two largest eigenvalues and the principal eigenvector of a symmetric 3x3
+__device__ __forceinline__ void lm_eigen_sym3_top(const double *A_in, double &l1, double &l2, double *v1)
+{
+    double A[9], Q[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = A_in[i];
+    for (int sweep = 0; sweep < 50; ++sweep) {
+        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+        if (off < 1e-300) break;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = A[3 * p + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double tau = (A[4 * q] - A[4 * p]) / (2 * apq);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1 + tau * tau));
+                const double c = 1 / sqrt(1 + t * t), s = t * c;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[3 * k + p], akq = A[3 * k + q];
+                    A[3 * k + p] = c * akp - s * akq;
+                    A[3 * k + q] = s * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[3 * p + k], aqk = A[3 * q + k];
+                    A[3 * p + k] = c * apk - s * aqk;
+                    A[3 * q + k] = s * apk + c * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double qkp = Q[3 * k + p], qkq = Q[3 * k + q];
+                    Q[3 * k + p] = c * qkp - s * qkq;
+                    Q[3 * k + q] = s * qkp + c * qkq;
+                }
+            }
+    }
+    // first maximum wins, then the first maximum of the rest (no dynamic indexing)
+    const double e0 = A[0], e1 = A[4], e2 = A[8];
+    int i1 = 0;
+    if (e1 > e0) i1 = 1;
+    if (e2 > (i1 == 1 ? e1 : e0)) i1 = 2;
+    const double ea = i1 == 0 ? e1 : e0, eb = i1 == 2 ? e1 : e2;  // the other two, in index order
+    l1 = i1 == 0 ? e0 : (i1 == 1 ? e1 : e2);
+    l2 = eb > ea ? eb : ea;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v1[k] = i1 == 0 ? Q[3 * k] : (i1 == 1 ? Q[3 * k + 1] : Q[3 * k + 2]);
+}
+
+// least squares of the 5x3 system A x = -1 (LM:870-875)
+__device__ __forceinline__ void lm_plane_fit5(double *A, double *x)
+{
+    double b[5] = {-1, -1, -1, -1, -1};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double nrm = 0;
+#pragma unroll
+        for (int i = k; i < 5; ++i) nrm += A[3 * i + k] * A[3 * i + k];
+        nrm = sqrt(nrm);
+        if (nrm == 0.0) continue;
+        const double alpha = A[3 * k + k] > 0 ? -nrm : nrm;
+        double v[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = k; i < 5; ++i) v[i] = A[3 * i + k];
+        v[k] -= alpha;
+        double vv = 0;
+#pragma unroll
+        for (int i = k; i < 5; ++i) vv += v[i] * v[i];
+        if (vv == 0.0) continue;
+#pragma unroll
+        for (int j = k; j < 3; ++j) {
+            double d = 0;
+#pragma unroll
+            for (int i = k; i < 5; ++i) d += v[i] * A[3 * i + j];
+            d = 2 * d / vv;
+#pragma unroll
+            for (int i = k; i < 5; ++i) A[3 * i + j] -= d * v[i];
+        }
+        double d = 0;
+#pragma unroll
+        for (int i = k; i < 5; ++i) d += v[i] * b[i];
+        d = 2 * d / vv;
+#pragma unroll
+        for (int i = k; i < 5; ++i) b[i] -= d * v[i];
+    }
+    x[0] = x[1] = x[2] = 0.0;
+#pragma unroll
+    for (int i = 2; i >= 0; --i) {
+        double acc = b[i];
+#pragma unroll
+        for (int j = i + 1; j < 3; ++j) acc -= A[3 * i + j] * x[j];
+        x[i] = A[3 * i + i] != 0.0 ? acc / A[3 * i + i] : 0.0;
+    }
+}
+
+struct LmTrig {
+    float srx, crx, sry, cry, srz, crz, tx, ty, tz;
+};
+
+__device__ __forceinline__ float4 lm_to_map(const LmTrig &g, float4 p)
+{
+    // LM:244-262
+    const float x1 = g.crz * p.x - g.srz * p.y;
+    const float y1 = g.srz * p.x + g.crz * p.y;
+    const float z1 = p.z;
+    const float x2 = x1;
+    const float y2 = g.crx * y1 - g.srx * z1;
+    const float z2 = g.srx * y1 + g.crx * z1;
+    return make_float4(g.cry * x2 + g.sry * z2 + g.tx, y2 + g.ty, -g.sry * x2 + g.cry * z2 + g.tz, p.w);
+}
+
+// one row of the mapping system (LM:940-966)
+__device__ __forceinline__ void lm_row(const LmTrig &g, float4 pt, float4 cf, double *sum)
+{
+    const float srx = g.srx, crx = g.crx, sry = g.sry, cry = g.cry, srz = g.srz, crz = g.crz;
+    const float px = pt.x, py = pt.y, pz = pt.z;
+    float a[6];
+    a[0] = (crx * sry * srz * px + crx * crz * sry * py - srx * sry * pz) * cf.x +
+           (-srx * srz * px - crz * srx * py - crx * pz) * cf.y +
+           (crx * cry * srz * px + crx * cry * crz * py - cry * srx * pz) * cf.z;
+    a[1] = ((cry * srx * srz - crz * sry) * px + (sry * srz + cry * crz * srx) * py + crx * cry * pz) * cf.x +
+           ((-cry * crz - srx * sry * srz) * px + (cry * srz - crz * srx * sry) * py - crx * sry * pz) * cf.z;
+    a[2] = ((crz * srx * sry - cry * srz) * px + (-cry * crz - srx * sry * srz) * py) * cf.x +
+           (crx * crz * px - crx * srz * py) * cf.y +
+           ((sry * srz + cry * crz * srx) * px + (crz * sry - cry * srx * srz) * py) * cf.z;
+    a[3] = cf.x;
+    a[4] = cf.y;
+    a[5] = cf.z;
+    const float b = -cf.w;
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) sum[k++] += (double)a[r] * (double)a[c];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) sum[21 + r] += (double)a[r] * (double)b;
+    sum[27] += 1.0;
+}
+
+struct MapDesc {
+    long long cstack_off, sstack_off, cmap_off, smap_off;  // into the packed float4 arrays
+    int nc, ns, mc, ms;
+};
+
+__global__ __launch_bounds__(LBLOCK) void loam_mapping_kernel(
+    const MapDesc *__restrict__ sweeps, const float4 *__restrict__ cstack, const float4 *__restrict__ sstack,
+    const float4 *__restrict__ cmap, const float4 *__restrict__ smap, const PairDesc *__restrict__ cpairs,
+    const float4 *__restrict__ csorted, const unsigned *__restrict__ ccells, const PairDesc *__restrict__ spairs,
+    const float4 *__restrict__ ssorted, const unsigned *__restrict__ scells, const float *__restrict__ tr_in,
+    float *__restrict__ tr_out, int *__restrict__ iters_out, int *__restrict__ nsel_out)
+{
+    __shared__ float tr[6];
+    __shared__ double red[LWAVES][LSUMS];
+    __shared__ double sA[36], sB[6], sX[6], sV[6], sQ[36], sP[36], sE[36];
+    __shared__ int s_flags[3];  // degenerate, done, last nsel
+    const int b = blockIdx.x;
+    const MapDesc D = sweeps[b];
+    const PairDesc &CP = cpairs[b];
+    const PairDesc &SP = spairs[b];
+    const float4 *cs = cstack + D.cstack_off, *ss = sstack + D.sstack_off, *cm = cmap + D.cmap_off,
+                 *sm = smap + D.smap_off;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 6) tr[threadIdx.x] = tr_in[6 * b + threadIdx.x];
+    if (threadIdx.x < 36) sP[threadIdx.x] = (threadIdx.x % 7 == 0) ? 1.0 : 0.0;
+    if (threadIdx.x == 0) {
+        s_flags[0] = 0;
+        s_flags[1] = 0;
+        s_flags[2] = 0;
+    }
+    __syncthreads();
+    int iters = 0;
+    const bool enough = D.mc > 10 && D.ms > 100;  // LM:748
+
+    for (int it = 0; enough && it < 10; ++it) {  // LM:752
+        ++iters;
+        double sum[LSUMS];
+#pragma unroll
+        for (int k = 0; k < LSUMS; ++k) sum[k] = 0.0;
+        LmTrig g;
+        g.srx = sinf(tr[0]); g.crx = cosf(tr[0]);
+        g.sry = sinf(tr[1]); g.cry = cosf(tr[1]);
+        g.srz = sinf(tr[2]); g.crz = cosf(tr[2]);
+        g.tx = tr[3]; g.ty = tr[4]; g.tz = tr[5];
+
+        // ---- corner features: line through the 5 nearest map corners (LM:756-858)
+        for (int i0 = 0; i0 < D.nc; i0 += LBLOCK) {
+            const int i = i0 + threadIdx.x;
+            const bool act = i < D.nc;
+            float4 po = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act) po = cs[i];
+            const float4 ps = lm_to_map(g, po);
+            Best<5> B;
+            B.init();
+            knn_query(CP, csorted, ccells, act, ps.x, ps.y, ps.z, B);
+            if (act && B.d[4] < 1.0f) {
+                float4 q[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) q[j] = cm[B.i[j]];
+                float cx = 0, cy = 0, cz = 0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    cx += q[j].x;
+                    cy += q[j].y;
+                    cz += q[j].z;
+                }
+                cx /= 5; cy /= 5; cz /= 5;
+                float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const float ax = q[j].x - cx, ay = q[j].y - cy, az = q[j].z - cz;
+                    a11 += ax * ax; a12 += ax * ay; a13 += ax * az;
+                    a22 += ay * ay; a23 += ay * az; a33 += az * az;
+                }
+                a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
+                const double A1[9] = {a11, a12, a13, a12, a22, a23, a13, a23, a33};
+                double l1, l2, v1[3];
+                lm_eigen_sym3_top(A1, l1, l2, v1);
+                if ((float)l1 > 3 * (float)l2) {  // LM:812
+                    const float x0 = ps.x, y0 = ps.y, z0 = ps.z;
+                    const float x1 = (float)((double)cx + 0.1 * (double)(float)v1[0]);
+                    const float y1 = (float)((double)cy + 0.1 * (double)(float)v1[1]);
+                    const float z1 = (float)((double)cz + 0.1 * (double)(float)v1[2]);
+                    const float x2 = (float)((double)cx - 0.1 * (double)(float)v1[0]);
+                    const float y2 = (float)((double)cy - 0.1 * (double)(float)v1[1]);
+                    const float z2 = (float)((double)cz - 0.1 * (double)(float)v1[2]);
+                    const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
+                    const float m22 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
+                    const float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
+                    const float a012 = sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
+                    const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+                    const float la = ((y1 - y2) * m11 + (z1 - z2) * m22) / a012 / l12;
+                    const float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) / a012 / l12;
+                    const float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) / a012 / l12;
+                    const float ld2 = a012 / l12;
+                    const float s = (float)(1 - 0.9 * fabs((double)ld2));
+                    if (s > 0.1) lm_row(g, po, make_float4(s * la, s * lb, s * lc, s * ld2), sum);
+                }
+            }
+        }
+        // ---- surface features: plane through the 5 nearest map surfels (LM:860-920)
+        for (int i0 = 0; i0 < D.ns; i0 += LBLOCK) {
+            const int i = i0 + threadIdx.x;
+            const bool act = i < D.ns;
+            float4 po = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act) po = ss[i];
+            const float4 ps = lm_to_map(g, po);
+            Best<5> B;
+            B.init();
+            knn_query(SP, ssorted, scells, act, ps.x, ps.y, ps.z, B);
+            if (act && B.d[4] < 1.0f) {
+                float4 q[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) q[j] = sm[B.i[j]];
+                double A0[15], x[3];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    A0[3 * j] = q[j].x;
+                    A0[3 * j + 1] = q[j].y;
+                    A0[3 * j + 2] = q[j].z;
+                }
+                lm_plane_fit5(A0, x);
+                float pa = (float)x[0], pb = (float)x[1], pc = (float)x[2], pd = 1;
+                const float pn = sqrtf(pa * pa + pb * pb + pc * pc);
+                pa /= pn; pb /= pn; pc /= pn; pd /= pn;
+                bool valid = true;
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    valid = valid && !((double)fabsf(pa * q[j].x + pb * q[j].y + pc * q[j].z + pd) > 0.2);
+                if (valid) {
+                    const float pd2 = pa * ps.x + pb * ps.y + pc * ps.z + pd;
+                    const float s = (float)(1 - 0.9 * fabs((double)pd2) /
+                                                    (double)sqrtf(sqrtf(ps.x * ps.x + ps.y * ps.y + ps.z * ps.z)));
+                    if (s > 0.1) lm_row(g, po, make_float4(s * pa, s * pb, s * pc, s * pd2), sum);
+                }
+            }
+        }
+        // ---- block reduction of the 28 sums (fixed order)
+#pragma unroll
+        for (int k = 0; k < LSUMS; ++k) {
+            const double v = wave_sum(sum[k]);
+            if (lane == 0) red[wave][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot[LSUMS];
+            for (int k = 0; k < LSUMS; ++k) {
+                double v = 0;
+                for (int w = 0; w < LWAVES; ++w) v += red[w][k];
+                tot[k] = v;
+            }
+            const int nsel = (int)tot[27];
+            s_flags[2] = nsel;
+            if (nsel >= 50) {  // LM:929-931
+                int k = 0;
+                for (int r = 0; r < 6; ++r)
+                    for (int c = r; c < 6; ++c) {
+                        sA[6 * r + c] = tot[k];
+                        sA[6 * c + r] = tot[k];
+                        ++k;
+                    }
+                for (int r = 0; r < 6; ++r) sB[r] = tot[21 + r];
+                if (it == 0) {  // LM:970-991: eigenvalues below 100 mark degenerate directions
+                    for (int i = 0; i < 36; ++i) sE[i] = sA[i];
+                    lo_eigen_sym6(sE, sQ);
+                    double ev[6];
+                    int order[6];
+                    for (int i = 0; i < 6; ++i) {
+                        ev[i] = sE[7 * i];
+                        order[i] = i;
+                    }
+                    for (int i = 0; i < 6; ++i)
+                        for (int j = i + 1; j < 6; ++j)
+                            if (ev[order[j]] > ev[order[i]]) {
+                                const int t = order[i];
+                                order[i] = order[j];
+                                order[j] = t;
+                            }
+                    int keep = 6;
+                    while (keep > 0 && ev[order[keep - 1]] < 100.0) --keep;
+                    s_flags[0] = keep < 6;
+                    for (int r = 0; r < 6; ++r)
+                        for (int c = 0; c < 6; ++c) {
+                            double acc = 0;
+                            for (int k2 = 0; k2 < keep; ++k2) acc += sQ[6 * r + order[k2]] * sQ[6 * c + order[k2]];
+                            sP[6 * r + c] = acc;
+                        }
+                }
+                lo_solve_qr6(sA, sB, sX, sV);  // LM:968
+                if (s_flags[0]) {              // LM:993-997
+                    double x2[6];
+                    for (int r = 0; r < 6; ++r) {
+                        double acc = 0;
+                        for (int c = 0; c < 6; ++c) acc += sP[6 * r + c] * sX[c];
+                        x2[r] = acc;
+                    }
+                    for (int r = 0; r < 6; ++r) sX[r] = x2[r];
+                }
+                float xf[6];
+                for (int k2 = 0; k2 < 6; ++k2) {
+                    xf[k2] = (float)sX[k2];
+                    tr[k2] = tr[k2] + xf[k2];
+                }
+                const double r2d = 180.0 / 3.14159265358979323846;
+                const float dR = (float)sqrt((xf[0] * r2d) * (xf[0] * r2d) + (xf[1] * r2d) * (xf[1] * r2d) +
+                                             (xf[2] * r2d) * (xf[2] * r2d));
+                const float dT = (float)sqrt(((double)xf[3] * 100) * ((double)xf[3] * 100) +
+                                             ((double)xf[4] * 100) * ((double)xf[4] * 100) +
+                                             ((double)xf[5] * 100) * ((double)xf[5] * 100));
+                if (dR < 0.05 && dT < 0.05) s_flags[1] = 1;  // LM:1015
+            }
+        }
+        __syncthreads();
+        if (s_flags[1]) break;
+    }
+    if (threadIdx.x < 6) tr_out[6 * b + threadIdx.x] = tr[threadIdx.x];
+    if (threadIdx.x == 0) {
+        if (iters_out) iters_out[b] = iters;
+        if (nsel_out) nsel_out[b] = s_flags[2];
+    }
+}
+
 __global__ void loam_to_end_kernel(const float *__restrict__ tr6, const float4 *__restrict__ in, int n,
                                    float4 *__restrict__ out, int to_end)
 {
@@ -549,6 +921,70 @@ extern "C" int gpscal_loam_odometry_batched(gpscal_ctx *ctx, int nsweeps, const 
     bool sync = true;
     GPSCAL_HIP(ctx, o_tr.commit(ctx, &sync));
     GPSCAL_HIP(ctx, o_sum.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, o_it.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, o_ns.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}
+
+extern "C" int gpscal_loam_mapping_batched(gpscal_ctx *ctx, int nsweeps, const float *corner_stack_xyzi,
+                                           const int *corner_stack_off, const float *surf_stack_xyzi,
+                                           const int *surf_stack_off, const float *corner_map_xyzi,
+                                           const int *corner_map_off, const float *surf_map_xyzi,
+                                           const int *surf_map_off, const float *transform_in, float *transform_out,
+                                           int *iters_out, int *nsel_out)
+{
+    if (!ctx || nsweeps < 1 || !corner_stack_xyzi || !corner_stack_off || !surf_stack_xyzi || !surf_stack_off ||
+        !corner_map_xyzi || !corner_map_off || !surf_map_xyzi || !surf_map_off || !transform_in || !transform_out)
+        return fail(ctx, GPSCAL_EINVAL, "gpscal_loam_mapping_batched: bad argument");
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    const int tc = corner_stack_off[nsweeps], ts = surf_stack_off[nsweeps], tcm = corner_map_off[nsweeps],
+              tsm = surf_map_off[nsweeps];
+    std::vector<MapDesc> hs(nsweeps);
+    std::vector<long long> coff(nsweeps + 1), soff(nsweeps + 1);
+    for (int b = 0; b <= nsweeps; ++b) {
+        coff[b] = corner_map_off[b];
+        soff[b] = surf_map_off[b];
+    }
+    for (int b = 0; b < nsweeps; ++b) {
+        MapDesc &D = hs[b];
+        D.cstack_off = corner_stack_off[b];
+        D.sstack_off = surf_stack_off[b];
+        D.cmap_off = corner_map_off[b];
+        D.smap_off = surf_map_off[b];
+        D.nc = corner_stack_off[b + 1] - corner_stack_off[b];
+        D.ns = surf_stack_off[b + 1] - surf_stack_off[b];
+        D.mc = corner_map_off[b + 1] - corner_map_off[b];
+        D.ms = surf_map_off[b + 1] - surf_map_off[b];
+        if (D.nc < 0 || D.ns < 0 || D.mc < 0 || D.ms < 0) return fail(ctx, GPSCAL_EINVAL, "bad offsets");
+    }
+    InArg<float> a_cs, a_ss, a_cm, a_sm, a_tr;
+    OutArg<float> o_tr;
+    OutArg<int> o_it, o_ns;
+    GPSCAL_HIP(ctx, a_cs.bind(ctx, corner_stack_xyzi, (size_t)std::max(tc, 1) * 4));
+    GPSCAL_HIP(ctx, a_ss.bind(ctx, surf_stack_xyzi, (size_t)std::max(ts, 1) * 4));
+    GPSCAL_HIP(ctx, a_cm.bind(ctx, corner_map_xyzi, (size_t)std::max(tcm, 1) * 4));
+    GPSCAL_HIP(ctx, a_sm.bind(ctx, surf_map_xyzi, (size_t)std::max(tsm, 1) * 4));
+    GPSCAL_HIP(ctx, a_tr.bind(ctx, transform_in, (size_t)nsweeps * 6));
+    GPSCAL_HIP(ctx, o_tr.bind(ctx, transform_out, (size_t)nsweeps * 6));
+    GPSCAL_HIP(ctx, o_it.bind(ctx, iters_out, iters_out ? nsweeps : 0));
+    GPSCAL_HIP(ctx, o_ns.bind(ctx, nsel_out, nsel_out ? nsweeps : 0));
+    // kdtreeCornerFromMap / kdtreeSurfFromMap (setInputCloud, LM:749-750) = two grid sets
+    GridSet cg, sg;
+    int rc = build_grids(ctx, a_cm.dev, 16, coff.data(), nsweeps, 0.f, MAX_LEVELS, cg);
+    if (!rc) rc = build_grids(ctx, a_sm.dev, 16, soff.data(), nsweeps, 0.f, MAX_LEVELS, sg);
+    if (rc) return rc;
+    DevBuf<MapDesc> d_sw;
+    GPSCAL_HIP(ctx, d_sw.alloc_async(nsweeps, ctx->stream));
+    GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, hs.data(), sizeof(MapDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(loam_mapping_kernel, dim3(nsweeps), dim3(LBLOCK), 0, ctx->stream, d_sw.p,
+                       reinterpret_cast<const float4 *>(a_cs.dev), reinterpret_cast<const float4 *>(a_ss.dev),
+                       reinterpret_cast<const float4 *>(a_cm.dev), reinterpret_cast<const float4 *>(a_sm.dev),
+                       cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p, sg.cell_start, a_tr.dev,
+                       o_tr.dev, o_it.dev, o_ns.dev);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    bool sync = true;
+    GPSCAL_HIP(ctx, o_tr.commit(ctx, &sync));
     GPSCAL_HIP(ctx, o_it.commit(ctx, &sync));
     GPSCAL_HIP(ctx, o_ns.commit(ctx, &sync));
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));

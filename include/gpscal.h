@@ -232,6 +232,23 @@ int gpscal_loam_odometry_batched(gpscal_ctx *ctx, int nsweeps,
                                  const float *transform_in, float *transform_out,
                                  int *iters_out, int *nsel_out,
                                  const float *transform_sum_in, float *transform_sum_out);
+/* Replaces the sweep-to-map optimisation loop of laserMapping (LM:748-1018) for nsweeps
+ * INDEPENDENT sweeps (one per SLAM segment) in one launch: pointAssociateToMap (LM:244-262),
+ * k=5 searches in the local corner / surface maps (kdtree*FromMap, LM:749-750,760,867), the
+ * covariance-eigenvector line test (LM:763-857), the 5-point plane fit (LM:866-919), the 6x6
+ * normal equations + QR solve (LM:922-968), the degeneracy projection with threshold 100 at
+ * iteration 0 (LM:970-997), the update and the 0.05 deg / 0.05 cm stop (LM:999-1017); at most
+ * 10 iterations, skipped when the maps hold <= 10 corner or <= 100 surface points (LM:748).
+ * *_stack = laserCloudCornerStack / laserCloudSurfStack (the down-sampled features of the
+ * sweep), *_map = laserCloudCornerFromMap / laserCloudSurfFromMap.  transform_in / _out are
+ * transformTobeMapped before / after the loop (float[6] per sweep). */
+int gpscal_loam_mapping_batched(gpscal_ctx *ctx, int nsweeps,
+                                const float *corner_stack_xyzi, const int *corner_stack_off,
+                                const float *surf_stack_xyzi, const int *surf_stack_off,
+                                const float *corner_map_xyzi, const int *corner_map_off,
+                                const float *surf_map_xyzi, const int *surf_map_off,
+                                const float *transform_in, float *transform_out,
+                                int *iters_out, int *nsel_out);
 /* TransformToStart (to_end = 0, LO:123-150) / TransformToEnd (to_end = 1, LO:156-227)
  * of n points with one transform. */
 int gpscal_loam_transform(gpscal_ctx *ctx, const float *transform6,

@@ -158,6 +158,10 @@ void orc_lo_transform_to_end(const float tr[6], const float *pi, float *po);
 int orc_lo_match(const float *sharp, int nc, const float *flat, int ns, const float *cornerLast, int mc,
                  const float *surfLast, int ms, const float tr_in[6], float tr_out[6], int *iters_out,
                  int *nsel_out);
+/* laserMapping's sweep-to-map optimisation loop (laserMapping.cpp:244-262, 748-1018):
+ * k=5 search, covariance-eigen line test / 5-point plane fit, 6x6 Gauss-Newton. */
+int orc_lm_match(const float *cornerStack, int nc, const float *surfStack, int ns, const float *cornerMap, int mc,
+                 const float *surfMap, int ms, const float tr_in[6], float tr_out[6], int *iters_out, int *nsel_out);
 /* Pose accumulation (laserOdometry.cpp:1035-1064, IMU terms zero). */
 void orc_lo_accumulate(const float sum_in[6], const float tr[6], float sum_out[6]);
 

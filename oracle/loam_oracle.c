@@ -439,3 +439,274 @@ void orc_lo_accumulate(const float sum_in[6], const float tr[6], float sum_out[6
     sum_out[4] = ty;
     sum_out[5] = tz;
 }
+
+/* =====================================================================
+ * laserMapping's sweep-to-map optimisation loop.
+ *   LM = src/gpsCalibration/src/lidar_slam/loam/laserMapping.cpp
+ * pointAssociateToMap LM:244-262; k=5 search + line test LM:757-858; plane fit
+ * LM:860-920; 6x6 system, solve, degeneracy (threshold 100), stop 0.05 LM:922-1018.
+ * cv::eigen on the 3x3 covariance and cv::solve(DECOMP_QR) on the 5x3 plane system are
+ * restated in float64 (cyclic Jacobi / Householder QR); parity unpinned (OpenCV absent).
+ * ===================================================================== */
+
+static void lm_to_map(const float tr[6], const float *pi, float *po)
+{
+    /* LM:244-262 */
+    float x1 = cosf(tr[2]) * pi[0] - sinf(tr[2]) * pi[1];
+    float y1 = sinf(tr[2]) * pi[0] + cosf(tr[2]) * pi[1];
+    float z1 = pi[2];
+    float x2 = x1;
+    float y2 = cosf(tr[0]) * y1 - sinf(tr[0]) * z1;
+    float z2 = sinf(tr[0]) * y1 + cosf(tr[0]) * z1;
+    po[0] = cosf(tr[1]) * x2 + sinf(tr[1]) * z2 + tr[3];
+    po[1] = y2 + tr[4];
+    po[2] = -sinf(tr[1]) * x2 + cosf(tr[1]) * z2 + tr[5];
+    po[3] = pi[3];
+}
+
+/* largest eigenpair test of a symmetric 3x3: returns l1, l2 (two largest) and v1 */
+static void eigen_sym3_top(const double A_in[9], double *l1, double *l2, double v1[3])
+{
+    double A[9], Q[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memcpy(A, A_in, sizeof A);
+    for (int sweep = 0; sweep < 50; ++sweep) {
+        double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double apq = A[3 * p + q];
+                if (fabs(apq) < 1e-300) continue;
+                double tau = (A[4 * q] - A[4 * p]) / (2 * apq);
+                double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1 + tau * tau));
+                double c = 1 / sqrt(1 + t * t), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    double akp = A[3 * k + p], akq = A[3 * k + q];
+                    A[3 * k + p] = c * akp - s * akq;
+                    A[3 * k + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double apk = A[3 * p + k], aqk = A[3 * q + k];
+                    A[3 * p + k] = c * apk - s * aqk;
+                    A[3 * q + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double qkp = Q[3 * k + p], qkq = Q[3 * k + q];
+                    Q[3 * k + p] = c * qkp - s * qkq;
+                    Q[3 * k + q] = s * qkp + c * qkq;
+                }
+            }
+    }
+    int i1 = 0;
+    for (int i = 1; i < 3; ++i)
+        if (A[4 * i] > A[4 * i1]) i1 = i;
+    int i2 = -1;
+    for (int i = 0; i < 3; ++i)
+        if (i != i1 && (i2 < 0 || A[4 * i] > A[4 * i2])) i2 = i;
+    *l1 = A[4 * i1];
+    *l2 = A[4 * i2];
+    for (int k = 0; k < 3; ++k) v1[k] = Q[3 * k + i1];
+}
+
+/* least squares of the 5x3 system A x = -1 (LM:870-875), Householder QR */
+static void plane_fit5(const double P[15], double x[3])
+{
+    double A[15], b[5] = {-1, -1, -1, -1, -1};
+    memcpy(A, P, sizeof A);
+    for (int k = 0; k < 3; ++k) {
+        double nrm = 0;
+        for (int i = k; i < 5; ++i) nrm += A[3 * i + k] * A[3 * i + k];
+        nrm = sqrt(nrm);
+        if (nrm == 0.0) continue;
+        double alpha = A[3 * k + k] > 0 ? -nrm : nrm;
+        double v[5] = {0, 0, 0, 0, 0};
+        for (int i = k; i < 5; ++i) v[i] = A[3 * i + k];
+        v[k] -= alpha;
+        double vv = 0;
+        for (int i = k; i < 5; ++i) vv += v[i] * v[i];
+        if (vv == 0.0) continue;
+        for (int j = k; j < 3; ++j) {
+            double d = 0;
+            for (int i = k; i < 5; ++i) d += v[i] * A[3 * i + j];
+            d = 2 * d / vv;
+            for (int i = k; i < 5; ++i) A[3 * i + j] -= d * v[i];
+        }
+        double d = 0;
+        for (int i = k; i < 5; ++i) d += v[i] * b[i];
+        d = 2 * d / vv;
+        for (int i = k; i < 5; ++i) b[i] -= d * v[i];
+    }
+    for (int i = 2; i >= 0; --i) {
+        double acc = b[i];
+        for (int j = i + 1; j < 3; ++j) acc -= A[3 * i + j] * x[j];
+        x[i] = A[3 * i + i] != 0.0 ? acc / A[3 * i + i] : 0.0;
+    }
+}
+
+int orc_lm_match(const float *cornerStack, int nc, const float *surfStack, int ns, const float *cornerMap, int mc,
+                 const float *surfMap, int ms, const float tr_in[6], float tr_out[6], int *iters_out, int *nsel_out)
+{
+    float tr[6];
+    memcpy(tr, tr_in, sizeof tr);
+    int iters = 0, nsel_last = 0;
+    if (!(mc > 10 && ms > 100)) { /* LM:748 */
+        memcpy(tr_out, tr, sizeof tr);
+        if (iters_out) *iters_out = 0;
+        if (nsel_out) *nsel_out = 0;
+        return 0;
+    }
+    float *c3 = (float *)malloc(sizeof(float) * 3 * (size_t)mc), *s3 = (float *)malloc(sizeof(float) * 3 * (size_t)ms);
+    for (int i = 0; i < mc; ++i) memcpy(c3 + 3 * i, cornerMap + 4 * i, 12);
+    for (int i = 0; i < ms; ++i) memcpy(s3 + 3 * i, surfMap + 4 * i, 12);
+    orc_kdtree *kc = orc_kdtree_build(c3, mc), *ks = orc_kdtree_build(s3, ms);
+    int degenerate = 0;
+    double P[36];
+    for (int i = 0; i < 36; ++i) P[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    for (int it = 0; it < 10; ++it) { /* LM:753 */
+        ++iters;
+        double AtA[36], AtB[6];
+        memset(AtA, 0, sizeof AtA);
+        memset(AtB, 0, sizeof AtB);
+        int nsel = 0;
+        const float srx = sinf(tr[0]), crx = cosf(tr[0]), sry = sinf(tr[1]), cry = cosf(tr[1]);
+        const float srz = sinf(tr[2]), crz = cosf(tr[2]);
+        for (int pass = 0; pass < 2; ++pass) {
+            const float *stack = pass == 0 ? cornerStack : surfStack;
+            const float *map = pass == 0 ? cornerMap : surfMap;
+            const int n = pass == 0 ? nc : ns;
+            const orc_kdtree *kd = pass == 0 ? kc : ks;
+            for (int i = 0; i < n; ++i) {
+                const float *po = stack + 4 * i;
+                float ps[4];
+                lm_to_map(tr, po, ps);
+                int32_t idx[5];
+                float sqd[5];
+                orc_kdtree_search(kd, ps, 1, 5, idx, sqd);
+                if (!(sqd[4] < 1.0)) continue; /* LM:762,869 */
+                float cf[4];
+                int ok = 0;
+                if (pass == 0) { /* LM:763-857 */
+                    float cx = 0, cy = 0, cz = 0;
+                    for (int j = 0; j < 5; ++j) {
+                        cx += map[4 * idx[j]];
+                        cy += map[4 * idx[j] + 1];
+                        cz += map[4 * idx[j] + 2];
+                    }
+                    cx /= 5; cy /= 5; cz /= 5;
+                    float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
+                    for (int j = 0; j < 5; ++j) {
+                        float ax = map[4 * idx[j]] - cx, ay = map[4 * idx[j] + 1] - cy, az = map[4 * idx[j] + 2] - cz;
+                        a11 += ax * ax; a12 += ax * ay; a13 += ax * az;
+                        a22 += ay * ay; a23 += ay * az; a33 += az * az;
+                    }
+                    a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
+                    double A1[9] = {a11, a12, a13, a12, a22, a23, a13, a23, a33}, l1, l2, v1[3];
+                    eigen_sym3_top(A1, &l1, &l2, v1);
+                    if ((float)l1 > 3 * (float)l2) { /* LM:812 */
+                        float x0 = ps[0], y0 = ps[1], z0 = ps[2];
+                        float x1 = cx + 0.1 * (float)v1[0], y1 = cy + 0.1 * (float)v1[1], z1 = cz + 0.1 * (float)v1[2];
+                        float x2 = cx - 0.1 * (float)v1[0], y2 = cy - 0.1 * (float)v1[1], z2 = cz - 0.1 * (float)v1[2];
+                        float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
+                        float m22 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
+                        float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
+                        float a012 = sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
+                        float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+                        float la = ((y1 - y2) * m11 + (z1 - z2) * m22) / a012 / l12;
+                        float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) / a012 / l12;
+                        float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) / a012 / l12;
+                        float ld2 = a012 / l12;
+                        float s = 1 - 0.9 * fabs(ld2);
+                        cf[0] = s * la; cf[1] = s * lb; cf[2] = s * lc; cf[3] = s * ld2;
+                        ok = s > 0.1;
+                    }
+                } else { /* LM:866-919 */
+                    double A0[15], x[3];
+                    for (int j = 0; j < 5; ++j)
+                        for (int k = 0; k < 3; ++k) A0[3 * j + k] = map[4 * idx[j] + k];
+                    plane_fit5(A0, x);
+                    float pa = (float)x[0], pb = (float)x[1], pc = (float)x[2], pd = 1;
+                    float pn = sqrtf(pa * pa + pb * pb + pc * pc);
+                    pa /= pn; pb /= pn; pc /= pn; pd /= pn;
+                    int valid = 1;
+                    for (int j = 0; j < 5; ++j)
+                        if (fabs(pa * map[4 * idx[j]] + pb * map[4 * idx[j] + 1] + pc * map[4 * idx[j] + 2] + pd) > 0.2) {
+                            valid = 0;
+                            break;
+                        }
+                    if (valid) {
+                        float pd2 = pa * ps[0] + pb * ps[1] + pc * ps[2] + pd;
+                        float s = 1 - 0.9 * fabs(pd2) / sqrtf(sqrtf(ps[0] * ps[0] + ps[1] * ps[1] + ps[2] * ps[2]));
+                        cf[0] = s * pa; cf[1] = s * pb; cf[2] = s * pc; cf[3] = s * pd2;
+                        ok = s > 0.1;
+                    }
+                }
+                if (!ok) continue;
+                ++nsel;
+                /* LM:940-966 */
+                const float px = po[0], py = po[1], pz = po[2];
+                float a[6];
+                a[0] = (crx * sry * srz * px + crx * crz * sry * py - srx * sry * pz) * cf[0] +
+                       (-srx * srz * px - crz * srx * py - crx * pz) * cf[1] +
+                       (crx * cry * srz * px + crx * cry * crz * py - cry * srx * pz) * cf[2];
+                a[1] = ((cry * srx * srz - crz * sry) * px + (sry * srz + cry * crz * srx) * py + crx * cry * pz) * cf[0] +
+                       ((-cry * crz - srx * sry * srz) * px + (cry * srz - crz * srx * sry) * py - crx * sry * pz) * cf[2];
+                a[2] = ((crz * srx * sry - cry * srz) * px + (-cry * crz - srx * sry * srz) * py) * cf[0] +
+                       (crx * crz * px - crx * srz * py) * cf[1] +
+                       ((sry * srz + cry * crz * srx) * px + (crz * sry - cry * srx * srz) * py) * cf[2];
+                a[3] = cf[0]; a[4] = cf[1]; a[5] = cf[2];
+                const float b = -cf[3];
+                for (int r = 0; r < 6; ++r) {
+                    for (int c = 0; c < 6; ++c) AtA[6 * r + c] += (double)a[r] * (double)a[c];
+                    AtB[r] += (double)a[r] * (double)b;
+                }
+            }
+        }
+        nsel_last = nsel;
+        if (nsel < 50) continue; /* LM:929-931 */
+        double X[6];
+        solve_qr6(AtA, AtB, X);
+        if (it == 0) { /* LM:970-991, threshold 100 */
+            double E[6], V[36], V2[36];
+            eigen_sym6(AtA, E, V);
+            memcpy(V2, V, sizeof V2);
+            degenerate = 0;
+            for (int i = 5; i >= 0; --i) {
+                if (E[i] < 100.0) {
+                    for (int j = 0; j < 6; ++j) V2[6 * i + j] = 0;
+                    degenerate = 1;
+                } else break;
+            }
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) {
+                    double acc = 0;
+                    for (int k = 0; k < 6; ++k) acc += V[6 * k + r] * V2[6 * k + c];
+                    P[6 * r + c] = acc;
+                }
+        }
+        if (degenerate) {
+            double X2[6];
+            memcpy(X2, X, sizeof X2);
+            for (int r = 0; r < 6; ++r) {
+                double acc = 0;
+                for (int c = 0; c < 6; ++c) acc += P[6 * r + c] * X2[c];
+                X[r] = acc;
+            }
+        }
+        float xf[6];
+        for (int k = 0; k < 6; ++k) {
+            xf[k] = (float)X[k];
+            tr[k] += xf[k];
+        }
+        const double r2d = 180.0 / M_PI;
+        float deltaR = sqrt(pow(xf[0] * r2d, 2) + pow(xf[1] * r2d, 2) + pow(xf[2] * r2d, 2));
+        float deltaT = sqrt(pow(xf[3] * 100, 2) + pow(xf[4] * 100, 2) + pow(xf[5] * 100, 2));
+        if (deltaR < 0.05 && deltaT < 0.05) break; /* LM:1015 */
+    }
+    memcpy(tr_out, tr, sizeof tr);
+    if (iters_out) *iters_out = iters;
+    if (nsel_out) *nsel_out = nsel_last;
+    orc_kdtree_free(kc);
+    orc_kdtree_free(ks);
+    free(c3);
+    free(s3);
+    return 0;
+}

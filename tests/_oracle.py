@@ -294,3 +294,13 @@ def lo_accumulate(sum_in, tr):
     out = np.empty(6, dtype=np.float32)
     lib().orc_lo_accumulate(_p(s, c_fp), _p(t, c_fp), _p(out, c_fp))
     return out
+
+
+def lm_match(corner_stack, surf_stack, corner_map, surf_map, tr_in=None):
+    a = [np.ascontiguousarray(x, dtype=np.float32) for x in (corner_stack, surf_stack, corner_map, surf_map)]
+    tr_in = np.zeros(6, dtype=np.float32) if tr_in is None else np.ascontiguousarray(tr_in, dtype=np.float32)
+    tr = np.empty(6, dtype=np.float32)
+    it, ns = C.c_int(0), C.c_int(0)
+    lib().orc_lm_match(_p(a[0], c_fp), len(a[0]), _p(a[1], c_fp), len(a[1]), _p(a[2], c_fp), len(a[2]),
+                       _p(a[3], c_fp), len(a[3]), _p(tr_in, c_fp), _p(tr, c_fp), C.byref(it), C.byref(ns))
+    return tr, it.value, ns.value

@@ -61,3 +61,28 @@ def test_loam_odometry_too_few_last_points_is_a_noop(ctx, sweeps):
     tin = np.array([[0.01, 0.02, 0.03, 0.1, 0.2, 0.3]], dtype=np.float32)
     tr, iters, nsel, _ = ctx.loam_odometry([Bs[0]["sharp"]], [Bs[0]["flat"]], [A["less_sharp"][:5]], [A["less_flat"][:50]], tin)
     assert iters[0] == 0 and np.array_equal(tr[0], tin[0])  # laserOdometry.cpp:569
+
+
+def test_loam_mapping_batched_matches_oracle(ctx, sweeps):
+    """laserMapping.cpp:748-1018: the map is a denser sweep of the same scene, the stacks are the
+    features of three other sweeps, each started from a perturbed transformTobeMapped."""
+    A, Bs = sweeps
+    M = synth.loam_sweep((0, 0, 0, 0, 0, 0), seed=3, n_az=1800)
+    n = len(Bs)
+    tin = np.array([[0.003, -0.01, 0.002, 0.08, -0.02, 0.12], [0, 0, 0, 0, 0, 0], [-0.004, 0.006, 0.0, -0.05, 0.03, -0.1]],
+                   dtype=np.float32)
+    tr, iters, nsel = ctx.loam_mapping([b["less_sharp"] for b in Bs], [b["flat"] for b in Bs],
+                                       [M["less_sharp"]] * n, [M["less_flat"]] * n, tin)
+    for k in range(n):
+        r_tr, r_it, r_ns = O.lm_match(Bs[k]["less_sharp"], Bs[k]["flat"], M["less_sharp"], M["less_flat"], tin[k])
+        assert iters[k] == r_it, (k, iters[k], r_it)
+        assert abs(int(nsel[k]) - r_ns) <= max(3, r_ns // 200), (k, nsel[k], r_ns)
+        assert np.abs(tr[k] - r_tr).max() < 2e-4, (k, tr[k], r_tr)
+        assert r_ns >= 50 and r_it >= 2
+
+
+def test_loam_mapping_small_map_is_a_noop(ctx, sweeps):
+    A, Bs = sweeps
+    tin = np.array([[0.01, 0.02, 0.03, 0.1, 0.2, 0.3]], dtype=np.float32)
+    tr, iters, nsel = ctx.loam_mapping([Bs[0]["less_sharp"]], [Bs[0]["flat"]], [A["less_sharp"][:10]], [A["less_flat"]], tin)
+    assert iters[0] == 0 and np.array_equal(tr[0], tin[0])  # laserMapping.cpp:748

@@ -298,3 +298,34 @@ def test_icp_recovers_transform():
     assert hist[-1] < hist[0]
     assert np.abs(T[:3, :3] - T_true[:3, :3]).max() < 2e-3
     assert np.abs(T[:3, 3] - T_true[:3, 3]).max() < 0.05
+
+
+# ------------------------------------------------------------------ LOAM loops
+def test_lo_oracle_recovers_sweep_motion():
+    """laserOdometry.cpp:585-1029 restated: the loop must pull the sweep-to-sweep transform towards
+    the motion the synthetic sweep was generated with (forward motion -> negative tz).  The steps
+    are damped (b = -0.05 d, LO:970), so 25 iterations do not finish the job: a second call warm-started
+    at the first answer keeps moving the same way, as the next sweep's initial guess does in LOAM."""
+    from gpscalibration_amd import synth
+    A = synth.loam_sweep((0, 0, 0, 0, 0, 0), seed=1)
+    B = synth.loam_sweep((0.004, 0.015, -0.003, 0.05, 0.01, 0.45), seed=10)
+    tr, it, ns = O.lo_match(B["sharp"], B["flat"], A["less_sharp"], A["less_flat"])
+    assert 2 <= it <= 25 and ns > 100
+    assert tr[5] < -0.1
+    tr2, it2, _ = O.lo_match(B["sharp"], B["flat"], A["less_sharp"], A["less_flat"], tr)
+    assert it2 <= 25 and -0.5 < tr2[5] < tr[5]
+
+
+def test_lm_oracle_converges_to_the_map_pose():
+    """laserMapping.cpp:748-1018 restated: features of a sweep taken at the map's own pose, started
+    from a perturbed transformTobeMapped, come back to (near) zero."""
+    from gpscalibration_amd import synth
+    M = synth.loam_sweep((0, 0, 0, 0, 0, 0), seed=3, n_az=1800)
+    B = synth.loam_sweep((0, 0, 0, 0, 0, 0), seed=2)
+    tr0 = np.array([0.003, -0.01, 0.002, 0.08, -0.02, 0.12], dtype=np.float32)
+    tr, it, ns = O.lm_match(B["less_sharp"], B["flat"], M["less_sharp"], M["less_flat"], tr0)
+    assert 2 <= it <= 10 and ns >= 50
+    assert np.abs(tr[:3]).max() < 2e-3 and np.abs(tr[3:]).max() < 2e-2
+    # too small a map: untouched (LM:748)
+    tr, it, _ = O.lm_match(B["less_sharp"], B["flat"], M["less_sharp"][:10], M["less_flat"], tr0)
+    assert it == 0 and np.array_equal(tr, tr0)
