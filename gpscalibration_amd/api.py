@@ -220,6 +220,43 @@ class Context:
                                                      _ptr(nsel)), "loam_mapping_batched")
         return tout, iters, nsel
 
+    def scan_registration(self, sweeps, less_flat_factor=2):
+        """Batched scanRegistration (scanRegistration.cpp:238-674).  `sweeps` = list of [n,3] float32 raw
+        sweeps.  Returns a list of dict(full, sharp, less_sharp, flat, less_flat) of [k,4] float32."""
+        ns = len(sweeps)
+        off = np.zeros(ns + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(a) for a in sweeps])
+        lfo = (off * less_flat_factor).astype(np.int32)
+        xyz = np.ascontiguousarray(np.concatenate(sweeps) if off[-1] else np.zeros((1, 3)), dtype=np.float32)
+        tot = max(int(off[-1]), 1)
+        full = np.empty((tot, 4), dtype=np.float32)
+        sharp = np.empty((ns, 1536, 4), dtype=np.float32)
+        lsharp = np.empty((ns, 1920, 4), dtype=np.float32)
+        flat = np.empty((ns, 3072, 4), dtype=np.float32)
+        lflat = np.empty((max(int(lfo[-1]), 1), 4), dtype=np.float32)
+        cnt = np.empty((ns, 5), dtype=np.int32)
+        self._ck(self._L.gpscal_scan_registration_batched(self._h, ns, _ptr(xyz), _ptr(off), _ptr(full), _ptr(sharp),
+                                                          _ptr(lsharp), _ptr(flat), _ptr(lflat), _ptr(lfo), _ptr(cnt)),
+                 "scan_registration_batched")
+        out = []
+        for b in range(ns):
+            out.append({"full": full[off[b]:off[b] + cnt[b, 0]].copy(), "sharp": sharp[b, :cnt[b, 1]].copy(),
+                        "less_sharp": lsharp[b, :cnt[b, 2]].copy(), "flat": flat[b, :cnt[b, 3]].copy(),
+                        "less_flat": lflat[lfo[b]:lfo[b] + cnt[b, 4]].copy()})
+        return out
+
+    def voxel_grid(self, clouds, leaf):
+        """Batched pcl::VoxelGrid with a cubic leaf.  `clouds` = list of [n,4] float32; returns a list."""
+        nc = len(clouds)
+        off = np.zeros(nc + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(a) for a in clouds])
+        pts = np.ascontiguousarray(np.concatenate(clouds) if off[-1] else np.zeros((1, 4)), dtype=np.float32)
+        out = np.empty_like(pts)
+        cnt = np.empty(nc, dtype=np.int32)
+        self._ck(self._L.gpscal_voxel_grid_batched(self._h, nc, _ptr(pts), _ptr(off), float(leaf), _ptr(out), _ptr(cnt)),
+                 "voxel_grid_batched")
+        return [out[off[c]:off[c] + cnt[c]].copy() for c in range(nc)]
+
     def loam_transform(self, transform6, pts_xyzi, to_end=False):
         t = np.ascontiguousarray(transform6, dtype=np.float32)
         p = np.ascontiguousarray(pts_xyzi, dtype=np.float32)

@@ -295,3 +295,87 @@ def loam_sweep(motion, seed=0, n_az=900, sensor_h=1.8):
         out["flat"].append(pts[plane_idx[::12]])
         out["less_flat"].append(pts[plane_idx[::3]])
     return {k: np.concatenate(v).astype(np.float32) for k, v in out.items()}
+
+
+# ------------------------------------------------------------------ raw LiDAR sweeps
+# beam elevations scanRegistration.cpp:307-325 maps to ring ids 0..15
+SR_RING_DEG = (-15, -13, -11, -9, -7, -5, -4, -3, -2, -1, 0, 1, 3, 5, 7, 9)
+
+
+def lidar_world(seed=0, length=400.0, half_width=9.0):
+    """A street along +x: ground z = 0, building boxes on both sides with random set-backs and gaps,
+    poles along the kerbs.  Returns dict(boxes[nb,5] = xmin,xmax,ymin,ymax,height; poles[np,3] = x,y,r)."""
+    rng = np.random.default_rng(seed)
+    boxes, poles = [], []
+    for side in (-1.0, 1.0):
+        x = -40.0
+        while x < length + 40.0:
+            w = rng.uniform(6.0, 18.0)
+            setback = rng.uniform(0.0, 4.0)
+            depth = rng.uniform(6.0, 12.0)
+            y0 = side * (half_width + setback)
+            y1 = side * (half_width + setback + depth)
+            boxes.append([x, x + w, min(y0, y1), max(y0, y1), rng.uniform(4.0, 12.0)])
+            x += w + rng.uniform(1.0, 5.0)
+        x = -35.0
+        while x < length + 35.0:
+            poles.append([x, side * (half_width - 1.5 + rng.uniform(-0.3, 0.3)), rng.uniform(0.08, 0.2)])
+            x += rng.uniform(9.0, 22.0)
+    # the street is closed at both ends so every azimuth returns something
+    boxes.append([-60.0, -45.0, -40.0, 40.0, 10.0])
+    boxes.append([length + 45.0, length + 60.0, -40.0, 40.0, 10.0])
+    return {"boxes": np.array(boxes), "poles": np.array(poles)}
+
+
+def raw_sweep(world, pos=(0.0, 0.0), yaw=0.0, vel=(0.0, 0.0), yaw_rate=0.0, seed=0, n_az=1800, sensor_h=1.8,
+              sigma=0.004, max_range=80.0, nan_every=0, period=0.1):
+    """One 16-ring sweep in the sensor frame (x forward, y left, z up), in firing order: azimuth
+    step by step (clockwise, as scanRegistration's ori = -atan2(y, x) assumes), 16 beams per step.
+    The sensor moves with `vel` (m/s, world) and turns with `yaw_rate` (rad/s) during the sweep.
+    Rays without a return inside max_range are dropped; `nan_every` > 0 replaces every such-th
+    point by NaNs (pcl::removeNaNFromPointCloud, SR:266).  float32 [n,3]."""
+    rng = np.random.default_rng(seed)
+    k = np.repeat(np.arange(n_az), 16)
+    ring = np.tile(np.arange(16), n_az)
+    s = k / n_az
+    phi = math.pi - 2 * math.pi * s  # sensor-frame azimuth, decreasing = clockwise
+    el = np.radians(np.array(SR_RING_DEG, dtype=np.float64))[ring]
+    ds = np.stack([np.cos(el) * np.cos(phi), np.cos(el) * np.sin(phi), np.sin(el)], axis=1)
+    psi = yaw + yaw_rate * period * s
+    c, sn = np.cos(psi), np.sin(psi)
+    d = np.stack([c * ds[:, 0] - sn * ds[:, 1], sn * ds[:, 0] + c * ds[:, 1], ds[:, 2]], axis=1)
+    o = np.stack([pos[0] + vel[0] * period * s, pos[1] + vel[1] * period * s, np.full(len(s), sensor_h)], axis=1)
+    best = np.full(len(s), np.inf)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lam = -o[:, 2] / d[:, 2]  # ground
+        best = np.where((lam > 0.3) & (lam < best), lam, best)
+        bx = world["boxes"]
+        near = bx[(bx[:, 1] > pos[0] - max_range) & (bx[:, 0] < pos[0] + max_range)]
+        for b in near:
+            t1 = (b[0] - o[:, 0]) / d[:, 0]
+            t2 = (b[1] - o[:, 0]) / d[:, 0]
+            t3 = (b[2] - o[:, 1]) / d[:, 1]
+            t4 = (b[3] - o[:, 1]) / d[:, 1]
+            t5 = (0.0 - o[:, 2]) / d[:, 2]
+            t6 = (b[4] - o[:, 2]) / d[:, 2]
+            tmin = np.maximum(np.maximum(np.minimum(t1, t2), np.minimum(t3, t4)), np.minimum(t5, t6))
+            tmax = np.minimum(np.minimum(np.maximum(t1, t2), np.maximum(t3, t4)), np.maximum(t5, t6))
+            hit = (tmax >= tmin) & (tmin > 0.3)
+            best = np.where(hit & (tmin < best), tmin, best)
+        pl = world["poles"]
+        for p in pl[(pl[:, 0] > pos[0] - max_range) & (pl[:, 0] < pos[0] + max_range)]:
+            ox, oy = o[:, 0] - p[0], o[:, 1] - p[1]
+            a = d[:, 0] ** 2 + d[:, 1] ** 2
+            bq = 2 * (ox * d[:, 0] + oy * d[:, 1])
+            cq = ox * ox + oy * oy - p[2] * p[2]
+            disc = bq * bq - 4 * a * cq
+            lam = (-bq - np.sqrt(np.where(disc > 0, disc, np.nan))) / (2 * a)
+            z = o[:, 2] + lam * d[:, 2]
+            hit = (disc > 0) & (lam > 0.3) & (z < 6.0) & (z > 0.0)
+            best = np.where(hit & (lam < best), lam, best)
+    keep = np.isfinite(best) & (best < max_range)
+    rngd = best[keep] + rng.normal(0, sigma, int(keep.sum()))
+    pts = (ds[keep] * rngd[:, None]).astype(np.float32)
+    if nan_every > 0:
+        pts[::nan_every] = np.nan
+    return pts

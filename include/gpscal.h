@@ -254,6 +254,32 @@ int gpscal_loam_mapping_batched(gpscal_ctx *ctx, int nsweeps,
 int gpscal_loam_transform(gpscal_ctx *ctx, const float *transform6,
                           const float *pts_xyzi, int n, float *out_xyzi, int to_end);
 
+/* ------------------------------------------------ scanRegistration, VoxelGrid */
+/* Replaces scanRegistration's laserCloudHandler (SR:238-674, IMU inactive) for nsweeps raw
+ * sweeps in one launch: NaN removal, start / end orientation (SR:262-281), ring id from the
+ * vertical angle table and relative time -> intensity (SR:284-363), ring concatenation
+ * (SR:444-447), 11-tap curvature and ring spans (SR:455-490), occluded / parallel-beam
+ * rejection (SR:492-548), the per-sector curvature sort and greedy picking of <= 16 sharp,
+ * <= 20 less-sharp, <= 32 flat points with +-5 neighbour suppression (SR:558-657), and
+ * VoxelGrid(0.2) of each ring's remaining points (SR:659-673).
+ * xyz = packed float[3] points in the sensor frame, firing order; xyz_off = nsweeps+1 point
+ * offsets.  Outputs are float[4] {x,y,z,intensity} in LOAM axes: full (laserCloud, sweep b at
+ * xyz_off[b]), sharp (1536 slots per sweep), less_sharp (1920), flat (3072), less_flat (sweep
+ * b at less_flat_off[b], capacity less_flat_off[b+1]-less_flat_off[b]; NULL = xyz_off).
+ * counts = nsweeps x 5 {full, sharp, less_sharp, flat, less_flat}.  GPSCAL_ESIZE if a sweep
+ * keeps more than 60000 points (POINTSNUM, common.h:15), GPSCAL_ERANGE on less_flat overflow. */
+int gpscal_scan_registration_batched(gpscal_ctx *ctx, int nsweeps,
+                                     const float *xyz, const int *xyz_off,
+                                     float *full_xyzi, float *sharp_xyzi,
+                                     float *less_sharp_xyzi, float *flat_xyzi,
+                                     float *less_flat_xyzi, const int *less_flat_off,
+                                     int *counts);
+/* pcl::VoxelGrid<PointXYZI> with a cubic leaf (SR:667-673; LM:1044-1058 downSizeFilterCorner /
+ * Surf / Map) over nclouds clouds: centroid of x, y, z, intensity per occupied cell, output
+ * ordered by cell id, written at the cloud's own offset; counts[c] = points kept. */
+int gpscal_voxel_grid_batched(gpscal_ctx *ctx, int nclouds, const float *pts_xyzi,
+                              const int *off, float leaf, float *out_xyzi, int *counts);
+
 /* ------------------------------------------------------------- multi-GPU */
 /* New (no reference counterpart): the one exchange of the sharded pipeline,
  * an RCCL all-gather of per-segment pose chains / fit results over xGMI

@@ -165,6 +165,21 @@ int orc_lm_match(const float *cornerStack, int nc, const float *surfStack, int n
 /* Pose accumulation (laserOdometry.cpp:1035-1064, IMU terms zero). */
 void orc_lo_accumulate(const float sum_in[6], const float tr[6], float sum_out[6]);
 
+/* ------------------------------------------- scanRegistration (SR) + VoxelGrid */
+/* scanRegistration.cpp:238-674 for one raw sweep (n_in x float[3], sensor axes, NaNs
+ * allowed): ring / time tagging, ring concatenation, curvature, occlusion rejection,
+ * per-sector picking, VoxelGrid(0.2) of the less-flat points per ring.  Outputs are
+ * float[4] {x,y,z,intensity} in LOAM axes; every buffer needs room for 4*n_in points
+ * (quirk: a missing ring makes the next ring index re-scan earlier rings). */
+int orc_sr_extract(const float *xyz, int n_in, float *full, int *n_full, float *sharp, int *n_sharp,
+                   float *less_sharp, int *n_less_sharp, float *flat, int *n_flat, float *less_flat,
+                   int *n_less_flat);
+/* pcl::VoxelGrid<PointXYZI>::filter with setLeafSize(leaf,leaf,leaf) (PCL 1.8.0
+ * voxel_grid.hpp applyFilter; SR:667-673, LM:1044-1058).  Output ordered by cell id;
+ * points of a cell are summed in input order.  Returns 1 when PCL would give up
+ * (more than INT_MAX cells) and copy the input. */
+int orc_voxel_grid(const float *pts_xyzi, int n, float leaf, float *out_xyzi, int *n_out);
+
 #ifdef __cplusplus
 }
 #endif

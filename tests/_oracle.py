@@ -304,3 +304,25 @@ def lm_match(corner_stack, surf_stack, corner_map, surf_map, tr_in=None):
     lib().orc_lm_match(_p(a[0], c_fp), len(a[0]), _p(a[1], c_fp), len(a[1]), _p(a[2], c_fp), len(a[2]),
                        _p(a[3], c_fp), len(a[3]), _p(tr_in, c_fp), _p(tr, c_fp), C.byref(it), C.byref(ns))
     return tr, it.value, ns.value
+
+
+def sr_extract(xyz):
+    """scanRegistration.cpp:238-674 on one raw sweep [n,3] float32 -> dict of [k,4] clouds."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    n = len(xyz)
+    names = ("full", "sharp", "less_sharp", "flat", "less_flat")
+    bufs = {k: np.zeros((4 * n + 16, 4), dtype=np.float32) for k in names}
+    cnt = {k: C.c_int(0) for k in names}
+    args = []
+    for k in names:
+        args += [_p(bufs[k], c_fp), C.byref(cnt[k])]
+    lib().orc_sr_extract(_p(xyz, c_fp), n, *args)
+    return {k: bufs[k][:cnt[k].value].copy() for k in names}
+
+
+def voxel_grid(pts, leaf):
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    out = np.zeros((max(len(pts), 1), 4), dtype=np.float32)
+    no = C.c_int(0)
+    rc = lib().orc_voxel_grid(_p(pts, c_fp), len(pts), C.c_float(leaf), _p(out, c_fp), C.byref(no))
+    return out[:no.value].copy(), rc
