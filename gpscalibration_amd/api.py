@@ -257,6 +257,34 @@ class Context:
                  "voxel_grid_batched")
         return [out[off[c]:off[c] + cnt[c]].copy() for c in range(nc)]
 
+    def loam_run(self, segments, stamps, corner_pool_cap=0, surf_pool_cap=0):
+        """The four LOAM nodes over pre-cut segments.  `segments` = list (one per segment) of lists of raw
+        sweeps [n,3] float32; `stamps` = list of per-segment stamp arrays.  Returns a list of dicts
+        (lo_sum, lm_aft, tm_mapped [n,6] float32; track [n,4] float64; lm_iters [n] int32) per segment."""
+        nseg = len(segments)
+        flat = [sw for seg in segments for sw in seg]
+        nsw = len(flat)
+        seg_off = np.zeros(nseg + 1, dtype=np.int32)
+        seg_off[1:] = np.cumsum([len(seg) for seg in segments])
+        off = np.zeros(nsw + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(a) for a in flat])
+        xyz = np.ascontiguousarray(np.concatenate(flat), dtype=np.float32)
+        st = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64) for x in stamps]))
+        lo = np.empty((nsw, 6), dtype=np.float32)
+        lm = np.empty((nsw, 6), dtype=np.float32)
+        tm = np.empty((nsw, 6), dtype=np.float32)
+        track = np.empty((nsw, 4), dtype=np.float64)
+        iters = np.empty(nsw, dtype=np.int32)
+        self._ck(self._L.gpscal_loam_run_batched(self._h, nseg, _ptr(xyz), _ptr(off), _ptr(seg_off), _ptr(st), _ptr(lo),
+                                                 _ptr(lm), _ptr(tm), _ptr(track), _ptr(iters), int(corner_pool_cap),
+                                                 int(surf_pool_cap)), "loam_run_batched")
+        out = []
+        for s in range(nseg):
+            a, b = seg_off[s], seg_off[s + 1]
+            out.append({"lo_sum": lo[a:b], "lm_aft": lm[a:b], "tm_mapped": tm[a:b], "track": track[a:b],
+                        "lm_iters": iters[a:b]})
+        return out
+
     def loam_transform(self, transform6, pts_xyzi, to_end=False):
         t = np.ascontiguousarray(transform6, dtype=np.float32)
         p = np.ascontiguousarray(pts_xyzi, dtype=np.float32)

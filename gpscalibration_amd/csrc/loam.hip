@@ -19,6 +19,7 @@
 #include "common.hpp"
 #include "knn_device.hpp"
 #include "knn_host.hpp"
+#include "loam_internal.hpp"
 #include "wave_reduce.hpp"
 
 #include <algorithm>
@@ -29,10 +30,6 @@ constexpr int LBLOCK = 512;
 constexpr int LWAVES = LBLOCK / 64;
 constexpr int LSUMS = 28;  // 21 upper-triangle AtA + 6 AtB + 1 row count
 
-struct SweepDesc {
-    long long sharp_off, flat_off, clast_off, slast_off;  // into the packed float4 arrays
-    int nc, ns, mc, ms;
-};
 
 __device__ __forceinline__ float4 lo_to_start(const float *tr, float4 p)
 {
@@ -622,10 +619,6 @@ __device__ __forceinline__ void lm_row(const LmTrig &g, float4 pt, float4 cf, do
     sum[27] += 1.0;
 }
 
-struct MapDesc {
-    long long cstack_off, sstack_off, cmap_off, smap_off;  // into the packed float4 arrays
-    int nc, ns, mc, ms;
-};
 
 __global__ __launch_bounds__(LBLOCK) void loam_mapping_kernel(
     const MapDesc *__restrict__ sweeps, const float4 *__restrict__ cstack, const float4 *__restrict__ sstack,
@@ -858,6 +851,39 @@ __global__ void loam_to_end_kernel(const float *__restrict__ tr6, const float4 *
 
 using namespace gpscal;
 
+namespace gpscal {
+
+int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, const float4 *d_sharp,
+                         const float4 *d_flat, const float4 *d_clast, const float4 *d_slast, const long long *coff,
+                         const long long *soff, const float *d_tr_in, float *d_tr_out, int *d_iters, int *d_nsel,
+                         const float *d_sum_in, float *d_sum_out)
+{
+    // the kd-trees of the last sweep (setInputCloud, LO:538-539,1119-1120) = two grid sets
+    GridSet cg, sg;
+    int rc = build_grids(ctx, d_clast, 16, coff, nsweeps, 0.f, MAX_LEVELS, cg);
+    if (!rc) rc = build_grids(ctx, d_slast, 16, soff, nsweeps, 0.f, MAX_LEVELS, sg);
+    if (rc) return rc;
+    long long ext_c = 0, ext_f = 0;
+    for (int b = 0; b < nsweeps; ++b) {
+        ext_c = std::max(ext_c, descs[b].sharp_off + descs[b].nc);
+        ext_f = std::max(ext_f, descs[b].flat_off + descs[b].ns);
+    }
+    DevBuf<SweepDesc> d_sw;
+    DevBuf<int> corr;
+    GPSCAL_HIP(ctx, d_sw.alloc_async(nsweeps, ctx->stream));
+    GPSCAL_HIP(ctx, corr.alloc_async((size_t)2 * ext_c + (size_t)3 * ext_f + 8, ctx->stream));
+    GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, descs, sizeof(SweepDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
+    // the grids index clouds relative to coff[0] / soff[0]
+    hipLaunchKernelGGL(loam_odometry_kernel, dim3(nsweeps), dim3(LBLOCK), 0, ctx->stream, d_sw.p, d_sharp, d_flat,
+                       d_clast, d_slast, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p, sg.cell_start,
+                       corr.p, d_tr_in, d_tr_out, d_iters, d_nsel, d_sum_in, d_sum_out);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the grid sets die with this scope
+    return GPSCAL_OK;
+}
+
+}  // namespace gpscal
+
 extern "C" int gpscal_loam_odometry_batched(gpscal_ctx *ctx, int nsweeps, const float *sharp_xyzi,
                                             const int *sharp_off, const float *flat_xyzi, const int *flat_off,
                                             const float *corner_last_xyzi, const int *corner_last_off,
@@ -902,22 +928,11 @@ extern "C" int gpscal_loam_odometry_batched(gpscal_ctx *ctx, int nsweeps, const 
     GPSCAL_HIP(ctx, o_sum.bind(ctx, transform_sum_out, transform_sum_out ? (size_t)nsweeps * 6 : 0));
     GPSCAL_HIP(ctx, o_it.bind(ctx, iters_out, iters_out ? nsweeps : 0));
     GPSCAL_HIP(ctx, o_ns.bind(ctx, nsel_out, nsel_out ? nsweeps : 0));
-    // the kd-trees of the last sweep (setInputCloud, LO:538-539,1119-1120) = two grid sets
-    GridSet cg, sg;
-    int rc = build_grids(ctx, a_cl.dev, 16, coff.data(), nsweeps, 0.f, MAX_LEVELS, cg);
-    if (!rc) rc = build_grids(ctx, a_sl.dev, 16, soff.data(), nsweeps, 0.f, MAX_LEVELS, sg);
+    int rc = loam_odometry_device(ctx, nsweeps, hs.data(), reinterpret_cast<const float4 *>(a_sh.dev),
+                                  reinterpret_cast<const float4 *>(a_fl.dev), reinterpret_cast<const float4 *>(a_cl.dev),
+                                  reinterpret_cast<const float4 *>(a_sl.dev), coff.data(), soff.data(), a_tr.dev,
+                                  o_tr.dev, o_it.dev, o_ns.dev, a_sum.dev, o_sum.dev);
     if (rc) return rc;
-    DevBuf<SweepDesc> d_sw;
-    DevBuf<int> corr;
-    GPSCAL_HIP(ctx, d_sw.alloc_async(nsweeps, ctx->stream));
-    GPSCAL_HIP(ctx, corr.alloc_async((size_t)2 * tc + (size_t)3 * tf + 8, ctx->stream));
-    GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, hs.data(), sizeof(SweepDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(loam_odometry_kernel, dim3(nsweeps), dim3(LBLOCK), 0, ctx->stream, d_sw.p,
-                       reinterpret_cast<const float4 *>(a_sh.dev), reinterpret_cast<const float4 *>(a_fl.dev),
-                       reinterpret_cast<const float4 *>(a_cl.dev), reinterpret_cast<const float4 *>(a_sl.dev),
-                       cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p, sg.cell_start, corr.p,
-                       a_tr.dev, o_tr.dev, o_it.dev, o_ns.dev, a_sum.dev, o_sum.dev);
-    GPSCAL_HIP(ctx, hipGetLastError());
     bool sync = true;
     GPSCAL_HIP(ctx, o_tr.commit(ctx, &sync));
     GPSCAL_HIP(ctx, o_sum.commit(ctx, &sync));
@@ -926,6 +941,30 @@ extern "C" int gpscal_loam_odometry_batched(gpscal_ctx *ctx, int nsweeps, const 
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GPSCAL_OK;
 }
+
+namespace gpscal {
+
+int loam_mapping_device(gpscal_ctx *ctx, int nsweeps, const MapDesc *descs, const float4 *d_cstack,
+                        const float4 *d_sstack, const float4 *d_cmap, const float4 *d_smap, const long long *cmoff,
+                        const long long *smoff, const float *d_tr_in, float *d_tr_out, int *d_iters, int *d_nsel)
+{
+    // kdtreeCornerFromMap / kdtreeSurfFromMap (setInputCloud, LM:749-750) = two grid sets
+    GridSet cg, sg;
+    int rc = build_grids(ctx, d_cmap, 16, cmoff, nsweeps, 0.f, MAX_LEVELS, cg);
+    if (!rc) rc = build_grids(ctx, d_smap, 16, smoff, nsweeps, 0.f, MAX_LEVELS, sg);
+    if (rc) return rc;
+    DevBuf<MapDesc> d_sw;
+    GPSCAL_HIP(ctx, d_sw.alloc_async(nsweeps, ctx->stream));
+    GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, descs, sizeof(MapDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(loam_mapping_kernel, dim3(nsweeps), dim3(LBLOCK), 0, ctx->stream, d_sw.p, d_cstack, d_sstack,
+                       d_cmap, d_smap, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p, sg.cell_start,
+                       d_tr_in, d_tr_out, d_iters, d_nsel);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}
+
+}  // namespace gpscal
 
 extern "C" int gpscal_loam_mapping_batched(gpscal_ctx *ctx, int nsweeps, const float *corner_stack_xyzi,
                                            const int *corner_stack_off, const float *surf_stack_xyzi,
@@ -969,20 +1008,11 @@ extern "C" int gpscal_loam_mapping_batched(gpscal_ctx *ctx, int nsweeps, const f
     GPSCAL_HIP(ctx, o_tr.bind(ctx, transform_out, (size_t)nsweeps * 6));
     GPSCAL_HIP(ctx, o_it.bind(ctx, iters_out, iters_out ? nsweeps : 0));
     GPSCAL_HIP(ctx, o_ns.bind(ctx, nsel_out, nsel_out ? nsweeps : 0));
-    // kdtreeCornerFromMap / kdtreeSurfFromMap (setInputCloud, LM:749-750) = two grid sets
-    GridSet cg, sg;
-    int rc = build_grids(ctx, a_cm.dev, 16, coff.data(), nsweeps, 0.f, MAX_LEVELS, cg);
-    if (!rc) rc = build_grids(ctx, a_sm.dev, 16, soff.data(), nsweeps, 0.f, MAX_LEVELS, sg);
+    int rc = loam_mapping_device(ctx, nsweeps, hs.data(), reinterpret_cast<const float4 *>(a_cs.dev),
+                                 reinterpret_cast<const float4 *>(a_ss.dev), reinterpret_cast<const float4 *>(a_cm.dev),
+                                 reinterpret_cast<const float4 *>(a_sm.dev), coff.data(), soff.data(), a_tr.dev,
+                                 o_tr.dev, o_it.dev, o_ns.dev);
     if (rc) return rc;
-    DevBuf<MapDesc> d_sw;
-    GPSCAL_HIP(ctx, d_sw.alloc_async(nsweeps, ctx->stream));
-    GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, hs.data(), sizeof(MapDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(loam_mapping_kernel, dim3(nsweeps), dim3(LBLOCK), 0, ctx->stream, d_sw.p,
-                       reinterpret_cast<const float4 *>(a_cs.dev), reinterpret_cast<const float4 *>(a_ss.dev),
-                       reinterpret_cast<const float4 *>(a_cm.dev), reinterpret_cast<const float4 *>(a_sm.dev),
-                       cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p, sg.cell_start, a_tr.dev,
-                       o_tr.dev, o_it.dev, o_ns.dev);
-    GPSCAL_HIP(ctx, hipGetLastError());
     bool sync = true;
     GPSCAL_HIP(ctx, o_tr.commit(ctx, &sync));
     GPSCAL_HIP(ctx, o_it.commit(ctx, &sync));

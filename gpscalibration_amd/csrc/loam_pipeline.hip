@@ -1,0 +1,966 @@
+// loam_pipeline.hip -- the four LOAM nodes (scanRegistration -> laserOdometry -> laserMapping
+// -> transformMaintenance) for many SLAM segments in lock step, device resident.  Segments are
+// independent (LOAM is reset per segment), sweeps inside a segment are sequential, so step t
+// of the pipeline processes sweep t of every segment with one launch per stage:
+//
+//   once      scan_registration_kernel over every sweep of every segment          (sr.hip)
+//   per t     loam_odometry_kernel (one workgroup per segment)                     (loam.hip)
+//             lo_post_kernel: TransformToEnd of the less-sharp / less-flat clouds  LO:1087-1114
+//             tm_kernel: transformMaintenance's handler + height compensation      TM:113-157, 267-314
+//   odd t     lm_prepare_kernel: transformAssociateToMap, cube ring shift, FOV cube list,
+//             map assembly, stack voxel filters                                    LM:420-745
+//             loam_mapping_kernel (one workgroup per segment)                      (loam.hip)
+//             lm_insert_kernel / lm_filter_kernel / lm_rebuild_kernel: cube insertion and
+//             the per-cube voxel filters                                           LM:1019-1079
+//
+// The 21 x 11 x 21 cube ring of laserMapping (LM:69-75) is one point pool per segment and cloud
+// type plus a (start, count) table per cube; a ring shift permutes the table, the per-sweep
+// rebuild writes the pool compactly into its double buffer.  Schedule and simplifications are
+// those DESIGN.md states for the CPU restatement (every node finishes a sweep before the next
+// one arrives; the odometry message's quaternion round trip is the identity; no IMU).
+#include "block_utils.hpp"
+#include "common.hpp"
+#include "knn_device.hpp"
+#include "loam_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace gpscal {
+
+constexpr int LW = 21, LH = 11, LDp = 21, LNUM = LW * LH * LDp;  // LM:72-75
+constexpr int MAXVALID = 125;
+
+struct SegState {
+    float lo_tr[6], lo_sum[6];                   // laserOdometry: transform, transformSum
+    float tSum[6], tTobe[6], tBef[6], tAft[6];   // laserMapping
+    int inited, cenW, cenH, cenD;
+    int cur;          // which pool / table buffer is current (both cloud types flip together)
+    int nvalid;
+    int valid[MAXVALID];
+    int active, ran;
+    float mBef[6], mAft[6];                      // transformMaintenance
+    double pre[4], tmpd[4];
+};
+
+struct PipeDims {
+    int nseg;
+    int cap[2];        // pool capacity per segment: corner, surf
+    int stack_cap[2];  // stack2 scratch capacity per segment
+    int key_cap[2];    // global sort-key capacity per segment
+};
+
+// per segment and cloud type (0 corner, 1 surf) views into the big buffers
+struct PipeBufs {
+    float4 *pool[2][2];       // [type][buffer], nseg * cap[type]
+    int *tab_start[2][2];     // [type][buffer], nseg * LNUM
+    int *tab_cnt[2][2];
+    float4 *frommap[2];       // nseg * cap[type]
+    float4 *stack2[2];        // nseg * stack_cap[type]
+    float4 *stack[2];         // nseg * stack_cap[type]
+    float4 *newq[2];          // nseg * stack_cap[type]: stack points in the map frame, sorted by cube
+    int *new_start[2], *new_cnt[2];  // nseg * LNUM
+    float4 *vin[2], *vout[2];        // nseg * (cap + stack_cap)
+    int *vin_off[2], *vin_cnt[2], *vout_cnt[2];  // nseg * MAXVALID
+    unsigned long long *keys[2];     // nseg * key_cap[type]
+    unsigned long long *vkeys[2];    // nseg * 2 * (cap + stack_cap)
+};
+
+// ---------------------------------------------------------------- small device math
+__device__ __forceinline__ void dev_assoc_to_map(const float *sum, const float *bef, const float *aft, float *out)
+{
+    // transformAssociateToMap, LM:116-203 == TM:178-265
+    float x1 = cosf(sum[1]) * (bef[3] - sum[3]) - sinf(sum[1]) * (bef[5] - sum[5]);
+    float y1 = bef[4] - sum[4];
+    float z1 = sinf(sum[1]) * (bef[3] - sum[3]) + cosf(sum[1]) * (bef[5] - sum[5]);
+    float x2 = x1;
+    float y2 = cosf(sum[0]) * y1 + sinf(sum[0]) * z1;
+    float z2 = -sinf(sum[0]) * y1 + cosf(sum[0]) * z1;
+    const float in3 = cosf(sum[2]) * x2 + sinf(sum[2]) * y2;
+    const float in4 = -sinf(sum[2]) * x2 + cosf(sum[2]) * y2;
+    const float in5 = z2;
+    const float sbcx = sinf(sum[0]), cbcx = cosf(sum[0]), sbcy = sinf(sum[1]), cbcy = cosf(sum[1]);
+    const float sbcz = sinf(sum[2]), cbcz = cosf(sum[2]);
+    const float sblx = sinf(bef[0]), cblx = cosf(bef[0]), sbly = sinf(bef[1]), cbly = cosf(bef[1]);
+    const float sblz = sinf(bef[2]), cblz = cosf(bef[2]);
+    const float salx = sinf(aft[0]), calx = cosf(aft[0]), saly = sinf(aft[1]), caly = cosf(aft[1]);
+    const float salz = sinf(aft[2]), calz = cosf(aft[2]);
+    const float srx = -sbcx * (salx * sblx + calx * cblx * salz * sblz + calx * calz * cblx * cblz) -
+                      cbcx * sbcy * (calx * calz * (cbly * sblz - cblz * sblx * sbly) -
+                                     calx * salz * (cbly * cblz + sblx * sbly * sblz) + cblx * salx * sbly) -
+                      cbcx * cbcy * (calx * salz * (cblz * sbly - cbly * sblx * sblz) -
+                                     calx * calz * (sbly * sblz + cbly * cblz * sblx) + cblx * cbly * salx);
+    out[0] = -asinf(srx);
+    const float srycrx = sbcx * (cblx * cblz * (caly * salz - calz * salx * saly) -
+                                 cblx * sblz * (caly * calz + salx * saly * salz) + calx * saly * sblx) -
+                         cbcx * cbcy * ((caly * calz + salx * saly * salz) * (cblz * sbly - cbly * sblx * sblz) +
+                                        (caly * salz - calz * salx * saly) * (sbly * sblz + cbly * cblz * sblx) -
+                                        calx * cblx * cbly * saly) +
+                         cbcx * sbcy * ((caly * calz + salx * saly * salz) * (cbly * cblz + sblx * sbly * sblz) +
+                                        (caly * salz - calz * salx * saly) * (cbly * sblz - cblz * sblx * sbly) +
+                                        calx * cblx * saly * sbly);
+    const float crycrx = sbcx * (cblx * sblz * (calz * saly - caly * salx * salz) -
+                                 cblx * cblz * (saly * salz + caly * calz * salx) + calx * caly * sblx) +
+                         cbcx * cbcy * ((saly * salz + caly * calz * salx) * (sbly * sblz + cbly * cblz * sblx) +
+                                        (calz * saly - caly * salx * salz) * (cblz * sbly - cbly * sblx * sblz) +
+                                        calx * caly * cblx * cbly) -
+                         cbcx * sbcy * ((saly * salz + caly * calz * salx) * (cbly * sblz - cblz * sblx * sbly) +
+                                        (calz * saly - caly * salx * salz) * (cbly * cblz + sblx * sbly * sblz) -
+                                        calx * caly * cblx * sbly);
+    out[1] = atan2f(srycrx / cosf(out[0]), crycrx / cosf(out[0]));
+    const float srzcrx = (cbcz * sbcy - cbcy * sbcx * sbcz) * (calx * salz * (cblz * sbly - cbly * sblx * sblz) -
+                                                               calx * calz * (sbly * sblz + cbly * cblz * sblx) +
+                                                               cblx * cbly * salx) -
+                         (cbcy * cbcz + sbcx * sbcy * sbcz) * (calx * calz * (cbly * sblz - cblz * sblx * sbly) -
+                                                               calx * salz * (cbly * cblz + sblx * sbly * sblz) +
+                                                               cblx * salx * sbly) +
+                         cbcx * sbcz * (salx * sblx + calx * cblx * salz * sblz + calx * calz * cblx * cblz);
+    const float crzcrx = (cbcy * sbcz - cbcz * sbcx * sbcy) * (calx * calz * (cbly * sblz - cblz * sblx * sbly) -
+                                                               calx * salz * (cbly * cblz + sblx * sbly * sblz) +
+                                                               cblx * salx * sbly) -
+                         (sbcy * sbcz + cbcy * cbcz * sbcx) * (calx * salz * (cblz * sbly - cbly * sblx * sblz) -
+                                                               calx * calz * (sbly * sblz + cbly * cblz * sblx) +
+                                                               cblx * cbly * salx) +
+                         cbcx * cbcz * (salx * sblx + calx * cblx * salz * sblz + calx * calz * cblx * cblz);
+    out[2] = atan2f(srzcrx / cosf(out[0]), crzcrx / cosf(out[0]));
+    x1 = cosf(out[2]) * in3 - sinf(out[2]) * in4;
+    y1 = sinf(out[2]) * in3 + cosf(out[2]) * in4;
+    z1 = in5;
+    x2 = x1;
+    y2 = cosf(out[0]) * y1 - sinf(out[0]) * z1;
+    z2 = sinf(out[0]) * y1 + cosf(out[0]) * z1;
+    out[3] = aft[3] - (cosf(out[1]) * x2 + sinf(out[1]) * z2);
+    out[4] = aft[4] - y2;
+    out[5] = aft[5] - (-sinf(out[1]) * x2 + cosf(out[1]) * z2);
+}
+
+struct Trig6 {
+    float s0, c0, s1, c1, s2, c2, t3, t4, t5;
+};
+__device__ __forceinline__ Trig6 trig_of(const float *tr)
+{
+    Trig6 g;
+    g.s0 = sinf(tr[0]); g.c0 = cosf(tr[0]);
+    g.s1 = sinf(tr[1]); g.c1 = cosf(tr[1]);
+    g.s2 = sinf(tr[2]); g.c2 = cosf(tr[2]);
+    g.t3 = tr[3]; g.t4 = tr[4]; g.t5 = tr[5];
+    return g;
+}
+__device__ __forceinline__ float4 dev_to_map(const Trig6 &g, float4 p)
+{
+    // pointAssociateToMap, LM:244-262
+    const float x1 = g.c2 * p.x - g.s2 * p.y;
+    const float y1 = g.s2 * p.x + g.c2 * p.y;
+    const float z1 = p.z;
+    const float x2 = x1;
+    const float y2 = g.c0 * y1 - g.s0 * z1;
+    const float z2 = g.s0 * y1 + g.c0 * z1;
+    return make_float4(g.c1 * x2 + g.s1 * z2 + g.t3, y2 + g.t4, -g.s1 * x2 + g.c1 * z2 + g.t5, p.w);
+}
+__device__ __forceinline__ float4 dev_to_be_mapped(const Trig6 &g, float4 p)
+{
+    // pointAssociateTobeMapped, LM:264-283
+    const float x1 = g.c1 * (p.x - g.t3) - g.s1 * (p.z - g.t5);
+    const float y1 = p.y - g.t4;
+    const float z1 = g.s1 * (p.x - g.t3) + g.c1 * (p.z - g.t5);
+    const float x2 = x1;
+    const float y2 = g.c0 * y1 + g.s0 * z1;
+    const float z2 = -g.s0 * y1 + g.c0 * z1;
+    return make_float4(g.c2 * x2 + g.s2 * y2, -g.s2 * x2 + g.c2 * y2, z2, p.w);
+}
+__device__ __forceinline__ int dev_cube_of(float v, int cen)
+{
+    int c = (int)(((double)v + 25.0) / 50.0) + cen;  // LM:489-495, 1025-1031
+    if ((double)v + 25.0 < 0) --c;
+    return c;
+}
+
+// TransformToEnd with the IMU stages dropped (LO:156-227), as in loam.hip
+__device__ __forceinline__ float4 dev_to_end(const float *tr, float4 p)
+{
+    const float s = 10 * (p.w - (int)p.w);
+    float rx = s * tr[0], ry = s * tr[1], rz = s * tr[2];
+    float tx = s * tr[3], ty = s * tr[4], tz = s * tr[5];
+    const float x1 = cosf(rz) * (p.x - tx) + sinf(rz) * (p.y - ty);
+    const float y1 = -sinf(rz) * (p.x - tx) + cosf(rz) * (p.y - ty);
+    const float z1 = (p.z - tz);
+    const float x2 = x1;
+    const float y2 = cosf(rx) * y1 + sinf(rx) * z1;
+    const float z2 = -sinf(rx) * y1 + cosf(rx) * z1;
+    const float x3 = cosf(ry) * x2 - sinf(ry) * z2, y3 = y2, z3 = sinf(ry) * x2 + cosf(ry) * z2;
+    rx = tr[0]; ry = tr[1]; rz = tr[2]; tx = tr[3]; ty = tr[4]; tz = tr[5];
+    const float x4 = cosf(ry) * x3 + sinf(ry) * z3;
+    const float y4 = y3;
+    const float z4 = -sinf(ry) * x3 + cosf(ry) * z3;
+    const float x5 = x4;
+    const float y5 = cosf(rx) * y4 - sinf(rx) * z4;
+    const float z5 = sinf(rx) * y4 + cosf(rx) * z4;
+    return make_float4(cosf(rz) * x5 - sinf(rz) * y5 + tx, sinf(rz) * x5 + cosf(rz) * y5 + ty, z5 + tz,
+                       (float)(int)p.w);
+}
+
+// ---------------------------------------------------------------- per-step kernels
+struct PostDesc {
+    long long src_c, src_s;  // less-sharp / less-flat of this sweep (float4 index)
+    long long dst_c, dst_s;  // into the new "last" buffers
+    int nc, ns, row, identity;
+};
+
+// LO:1087-1114 (identity != 0: the first sweep seeds the last clouds untransformed, LO:519-538);
+// also stores laserOdometry's transformSum of the sweep.
+__global__ void lo_post_kernel(const PostDesc *__restrict__ descs, const SegState *__restrict__ st,
+                               const float4 *__restrict__ lsharp, const float4 *__restrict__ lflat,
+                               float4 *__restrict__ clast, float4 *__restrict__ slast, float *__restrict__ lo_sum_out)
+{
+    const int s = blockIdx.y;
+    const PostDesc D = descs[s];
+    if (D.row < 0) return;
+    __shared__ float tr[6];
+    if (threadIdx.x < 6) tr[threadIdx.x] = st[s].lo_tr[threadIdx.x];
+    __syncthreads();
+    const int n = D.nc + D.ns;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const bool corner = i < D.nc;
+        const int j = corner ? i : i - D.nc;
+        float4 p = corner ? lsharp[D.src_c + j] : lflat[D.src_s + j];
+        if (!D.identity) p = dev_to_end(tr, p);
+        if (corner) clast[D.dst_c + j] = p;
+        else slast[D.dst_s + j] = p;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 6 && lo_sum_out) lo_sum_out[6 * (long long)D.row + threadIdx.x] = st[s].lo_sum[threadIdx.x];
+}
+
+// transformMaintenance: laserOdometryHandler (TM:267-314) + SaveTrailWithTimeTotxt (TM:113-157)
+__global__ void tm_kernel(SegState *__restrict__ st, const int *__restrict__ rows, const double *__restrict__ stamps,
+                          int nseg, float *__restrict__ tm_out, double *__restrict__ track_out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    const int row = rows[s];
+    if (row < 0) return;
+    SegState &S = st[s];
+    float sum[6];
+    for (int k = 0; k < 6; ++k) sum[k] = S.lo_sum[k];
+    if (fabs((double)sum[3]) < 0.000001 && fabs((double)sum[4]) < 0.000001 && fabs((double)sum[5]) < 0.000001) {
+        S.pre[3] = 0;
+        for (int k = 0; k < 6; ++k) S.mBef[k] = S.mAft[k] = 0.f;
+    }
+    float mapped[6];
+    dev_assoc_to_map(sum, S.mBef, S.mAft, mapped);
+    if (tm_out)
+        for (int k = 0; k < 6; ++k) tm_out[6 * (long long)row + k] = mapped[k];
+    const double px = mapped[5], py = mapped[3], pz = mapped[4], stamp = stamps[row];
+    if (S.pre[3] == 0) {
+        S.pre[0] = px; S.pre[1] = py; S.pre[2] = pz; S.pre[3] = stamp;
+        for (int k = 0; k < 4; ++k) S.tmpd[k] = S.pre[k];
+    } else {
+        const double dX = px - S.pre[0], dY = py - S.pre[1], dZ = pz - S.pre[2];
+        const double n3 = sqrt(dX * dX + dY * dY + dZ * dZ), n2 = sqrt(dX * dX + dY * dY);
+        S.tmpd[0] += dX * n3 / n2;
+        S.tmpd[1] += dY * n3 / n2;
+        S.tmpd[2] = pz;
+        S.tmpd[3] = stamp;
+        S.pre[0] = px; S.pre[1] = py; S.pre[2] = pz; S.pre[3] = stamp;
+    }
+    track_out[4 * (long long)row] = S.tmpd[0];
+    track_out[4 * (long long)row + 1] = S.tmpd[1];
+    track_out[4 * (long long)row + 2] = 10.0;  // HEIGHT, common.h:16
+    track_out[4 * (long long)row + 3] = S.tmpd[3];
+}
+
+struct PrepDesc {
+    long long clast_off, slast_off;
+    int nc, ns, active, pad;
+};
+
+// LM:420-745 for one segment: state reset, transformAssociateToMap, ring shift, FOV cube list,
+// map assembly, stack transform + voxel filters.  sizes[s] = {map corner, map surf, stack corner,
+// stack surf}.
+__global__ __launch_bounds__(SBLOCK) void lm_prepare_kernel(const PrepDesc *__restrict__ descs, SegState *__restrict__ st,
+                                                            PipeDims dims, PipeBufs B, const float4 *__restrict__ clast,
+                                                            const float4 *__restrict__ slast, int *__restrict__ sizes,
+                                                            int *__restrict__ status)
+{
+    extern __shared__ unsigned long long dyn_lds[];
+    __shared__ BlockShared S;
+    __shared__ float tTobe[6];
+    __shared__ int s_shift[3], s_reset, s_valid[MAXVALID], s_nvalid, s_voff[2][MAXVALID + 1], s_cnt;
+    const int s = blockIdx.x;
+    const PrepDesc D = descs[s];
+    SegState &G = st[s];
+    if (threadIdx.x == 0) {
+        G.active = D.active;
+        S.overflow = 0;
+    }
+    if (!D.active) {
+        if (threadIdx.x < 4) sizes[4 * s + threadIdx.x] = 0;
+        if (threadIdx.x == 0) G.nvalid = 0;
+        return;
+    }
+    const int cur = G.cur;
+    if (threadIdx.x == 0) {
+        float sum[6];
+        for (int k = 0; k < 6; ++k) sum[k] = G.lo_sum[k];
+        if (fabs((double)sum[3]) < 0.000001 && fabs((double)sum[4]) < 0.000001 && fabs((double)sum[5]) < 0.000001)
+            G.inited = 0;  // LM:316-319
+        for (int k = 0; k < 6; ++k) G.tSum[k] = sum[k];
+        s_reset = 0;
+        if (!G.inited) {  // LM:435-461
+            G.inited = 1;
+            s_reset = 1;
+            G.cenW = 10; G.cenH = 5; G.cenD = 10;
+            for (int k = 0; k < 6; ++k) G.tTobe[k] = G.tBef[k] = G.tAft[k] = 0.f;
+        }
+        float tobe[6];
+        dev_assoc_to_map(sum, G.tBef, G.tAft, tobe);  // LM:465
+        for (int k = 0; k < 6; ++k) {
+            G.tTobe[k] = tobe[k];
+            tTobe[k] = tobe[k];
+        }
+        const Trig6 g = trig_of(tobe);
+        const float4 pY = dev_to_map(g, make_float4(0.f, 10.f, 0.f, 0.f));  // LM:483-487
+        int cI = dev_cube_of(tobe[3], G.cenW), cJ = dev_cube_of(tobe[4], G.cenH), cK = dev_cube_of(tobe[5], G.cenD);
+        int dI = 0, dJ = 0, dK = 0;  // LM:497-651
+        while (cI < 3) { ++dI; ++cI; ++G.cenW; }
+        while (cI >= LW - 3) { --dI; --cI; --G.cenW; }
+        while (cJ < 3) { ++dJ; ++cJ; ++G.cenH; }
+        while (cJ >= LH - 3) { --dJ; --cJ; --G.cenH; }
+        while (cK < 3) { ++dK; ++cK; ++G.cenD; }
+        while (cK >= LDp - 3) { --dK; --cK; --G.cenD; }
+        s_shift[0] = dI; s_shift[1] = dJ; s_shift[2] = dK;
+        int nv = 0;
+        for (int i = cI - 2; i <= cI + 2; ++i)  // LM:653-712
+            for (int j = cJ - 2; j <= cJ + 2; ++j)
+                for (int k = cK - 2; k <= cK + 2; ++k) {
+                    if (!(i >= 0 && i < LW && j >= 0 && j < LH && k >= 0 && k < LDp)) continue;
+                    const float centerX = (float)(50.0 * (i - G.cenW)), centerY = (float)(50.0 * (j - G.cenH)),
+                                centerZ = (float)(50.0 * (k - G.cenD));
+                    bool inFOV = false;
+                    for (int ii = -1; ii <= 1; ii += 2)
+                        for (int jj = -1; jj <= 1; jj += 2)
+                            for (int kk = -1; kk <= 1; kk += 2) {
+                                const float cX = (float)((double)centerX + 25.0 * ii), cY = (float)((double)centerY + 25.0 * jj),
+                                            cZ = (float)((double)centerZ + 25.0 * kk);
+                                const float s1 = (tobe[3] - cX) * (tobe[3] - cX) + (tobe[4] - cY) * (tobe[4] - cY) +
+                                                 (tobe[5] - cZ) * (tobe[5] - cZ);
+                                const float s2 = (pY.x - cX) * (pY.x - cX) + (pY.y - cY) * (pY.y - cY) + (pY.z - cZ) * (pY.z - cZ);
+                                const float check1 = (float)(100.0 + (double)s1 - (double)s2 - 10.0 * sqrt(3.0) * (double)sqrtf(s1));
+                                const float check2 = (float)(100.0 + (double)s1 - (double)s2 + 10.0 * sqrt(3.0) * (double)sqrtf(s1));
+                                if (check1 < 0 && check2 > 0) inFOV = true;
+                            }
+                    if (inFOV) s_valid[nv++] = i + LW * j + LW * LH * k;
+                }
+        s_nvalid = nv;
+        G.nvalid = nv;
+        for (int k = 0; k < nv; ++k) G.valid[k] = s_valid[k];
+    }
+    __syncthreads();
+    // ---- ring shift of both tables (register staged, in place)
+    {
+        const int dI = s_shift[0], dJ = s_shift[1], dK = s_shift[2];
+        for (int type = 0; type < 2; ++type) {
+            int *ts = B.tab_start[type][cur] + (long long)s * LNUM, *tc = B.tab_cnt[type][cur] + (long long)s * LNUM;
+            int rs[(LNUM + SBLOCK - 1) / SBLOCK], rc[(LNUM + SBLOCK - 1) / SBLOCK];
+#pragma unroll
+            for (int u = 0; u < (LNUM + SBLOCK - 1) / SBLOCK; ++u) {
+                const int c = threadIdx.x + u * SBLOCK;
+                rs[u] = 0;
+                rc[u] = 0;
+                if (c < LNUM && !s_reset) {
+                    const int i = c % LW, j = (c / LW) % LH, k = c / (LW * LH);
+                    const int si = i - dI, sj = j - dJ, sk = k - dK;
+                    if (si >= 0 && si < LW && sj >= 0 && sj < LH && sk >= 0 && sk < LDp) {
+                        const int src = si + LW * sj + LW * LH * sk;
+                        rs[u] = ts[src];
+                        rc[u] = tc[src];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < (LNUM + SBLOCK - 1) / SBLOCK; ++u) {
+                const int c = threadIdx.x + u * SBLOCK;
+                if (c < LNUM) {
+                    ts[c] = rs[u];
+                    tc[c] = rc[u];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- map assembly: the valid cubes, in list order (LM:714-719)
+    const int nvalid = s_nvalid;
+    if (threadIdx.x < 2) {
+        const int type = threadIdx.x;
+        const int *tc = B.tab_cnt[type][cur] + (long long)s * LNUM;
+        int acc = 0;
+        for (int k = 0; k < nvalid; ++k) {
+            s_voff[type][k] = acc;
+            acc += tc[s_valid[k]];
+        }
+        s_voff[type][nvalid] = acc;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int type = 0; type < 2; ++type) {
+        const int *ts = B.tab_start[type][cur] + (long long)s * LNUM, *tc = B.tab_cnt[type][cur] + (long long)s * LNUM;
+        const float4 *pool = B.pool[type][cur] + (long long)s * dims.cap[type];
+        float4 *dst = B.frommap[type] + (long long)s * dims.cap[type];
+        for (int k = wave; k < nvalid; k += SWAVES) {
+            const int c = s_valid[k], st0 = ts[c], cn = tc[c], o = s_voff[type][k];
+            for (int i = lane; i < cn; i += 64) dst[o + i] = pool[st0 + i];
+        }
+    }
+    // ---- stack: last clouds -> map frame -> back (LM:466-478, 723-731), then VoxelGrid 0.2 / 0.4
+    const Trig6 g = trig_of(tTobe);
+    for (int type = 0; type < 2; ++type) {
+        const float4 *src = type == 0 ? clast + D.clast_off : slast + D.slast_off;
+        const int n = type == 0 ? D.nc : D.ns;
+        float4 *s2 = B.stack2[type] + (long long)s * dims.stack_cap[type];
+        for (int i = threadIdx.x; i < n; i += SBLOCK) s2[i] = dev_to_be_mapped(g, dev_to_map(g, src[i]));
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        block_voxel_grid(S, s2, n, type == 0 ? 0.2f : 0.4f, B.stack[type] + (long long)s * dims.stack_cap[type],
+                         dims.stack_cap[type], &s_cnt, dyn_lds, B.keys[type] + (long long)s * dims.key_cap[type],
+                         dims.key_cap[type]);
+        __syncthreads();
+        if (threadIdx.x == 0) sizes[4 * s + 2 + type] = s_cnt;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sizes[4 * s] = s_voff[0][nvalid];
+        sizes[4 * s + 1] = s_voff[1][nvalid];
+        if (S.overflow) atomicOr(status, 4);
+    }
+}
+
+// packs the per-segment map / stack slots into the contiguous arrays the grid build wants
+struct PackDesc {
+    long long dst[4];  // map corner, map surf, stack corner, stack surf
+    int n[4];
+};
+__global__ void lm_pack_kernel(const PackDesc *__restrict__ descs, PipeDims dims, PipeBufs B, float4 *__restrict__ cmap,
+                               float4 *__restrict__ smap, float4 *__restrict__ cstack, float4 *__restrict__ sstack)
+{
+    const int s = blockIdx.y;
+    const PackDesc D = descs[s];
+    for (int which = 0; which < 4; ++which) {
+        const int type = which & 1;
+        const float4 *src = which < 2 ? B.frommap[type] + (long long)s * dims.cap[type]
+                                      : B.stack[type] + (long long)s * dims.stack_cap[type];
+        float4 *dst = (which == 0 ? cmap : which == 1 ? smap : which == 2 ? cstack : sstack) + D.dst[which];
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < D.n[which]; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    }
+}
+
+// LM:1019-1058 for one segment: transformUpdate, then the stack points go to the map frame and
+// are grouped by cube (stable), and the inputs of the per-cube voxel filters are laid out.
+__global__ __launch_bounds__(SBLOCK) void lm_insert_kernel(SegState *__restrict__ st, PipeDims dims, PipeBufs B,
+                                                           const int *__restrict__ sizes, const float *__restrict__ tr_out,
+                                                           const int *__restrict__ iters, const int *__restrict__ rows,
+                                                           float *__restrict__ lm_aft_out, int *__restrict__ lm_iters_out,
+                                                           int *__restrict__ status)
+{
+    extern __shared__ unsigned long long dyn_lds[];
+    __shared__ float tTobe[6];
+    __shared__ int s_voff[MAXVALID + 1];
+    const int s = blockIdx.x;
+    SegState &G = st[s];
+    if (!G.active) return;
+    const int cur = G.cur;
+    if (threadIdx.x == 0) {
+        const bool ran = sizes[4 * s] > 10 && sizes[4 * s + 1] > 100;  // LM:748
+        G.ran = ran;
+        if (ran) {
+            for (int k = 0; k < 6; ++k) {  // transformUpdate, LM:238-241
+                G.tTobe[k] = tr_out[6 * s + k];
+                G.tBef[k] = G.tSum[k];
+                G.tAft[k] = G.tTobe[k];
+            }
+        }
+        for (int k = 0; k < 6; ++k) {
+            tTobe[k] = G.tTobe[k];
+            // odomAftMappedHandler, TM:316-337: the correction reaches transformMaintenance
+            G.mAft[k] = G.tAft[k];
+            G.mBef[k] = G.tBef[k];
+        }
+        const int row = rows[s];
+        if (row >= 0) {
+            if (lm_aft_out)
+                for (int k = 0; k < 6; ++k) lm_aft_out[6 * (long long)row + k] = G.tAft[k];
+            if (lm_iters_out) lm_iters_out[row] = ran ? iters[s] : 0;
+        }
+    }
+    __syncthreads();
+    const Trig6 g = trig_of(tTobe);
+    const int nvalid = G.nvalid;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int type = 0; type < 2; ++type) {
+        const int n = sizes[4 * s + 2 + type];
+        const float4 *stack = B.stack[type] + (long long)s * dims.stack_cap[type];
+        float4 *s2 = B.stack2[type] + (long long)s * dims.stack_cap[type];  // reused: map-frame points, stack order
+        float4 *newq = B.newq[type] + (long long)s * dims.stack_cap[type];
+        int *ns = B.new_start[type] + (long long)s * LNUM, *nc = B.new_cnt[type] + (long long)s * LNUM;
+        const int np2 = next_pow2(max(n, 1));
+        unsigned long long *K = np2 <= LDS_KEYS ? dyn_lds : B.keys[type] + (long long)s * dims.key_cap[type];
+        if (np2 > LDS_KEYS && np2 > dims.key_cap[type]) {
+            if (threadIdx.x == 0) atomicOr(status, 4);
+            return;
+        }
+        for (int c = threadIdx.x; c < LNUM; c += SBLOCK) {
+            ns[c] = 0;
+            nc[c] = 0;
+        }
+        for (int i = threadIdx.x; i < np2; i += SBLOCK) {
+            unsigned long long key = ~0ull;
+            if (i < n) {
+                const float4 q = dev_to_map(g, stack[i]);
+                s2[i] = q;
+                const int a = dev_cube_of(q.x, G.cenW), b = dev_cube_of(q.y, G.cenH), c = dev_cube_of(q.z, G.cenD);
+                if (a >= 0 && a < LW && b >= 0 && b < LH && c >= 0 && c < LDp)
+                    key = ((unsigned long long)(unsigned)(a + LW * b + LW * LH * c) << 32) | (unsigned)i;
+            }
+            K[i] = key;
+        }
+        __syncthreads();
+        block_bitonic_sort(K, np2);
+        for (int j = threadIdx.x; j < n; j += SBLOCK) {
+            const unsigned long long k = K[j];
+            if (k == ~0ull) continue;
+            newq[j] = s2[(unsigned)k];
+            const unsigned cube = (unsigned)(k >> 32);
+            if (j == 0 || (unsigned)(K[j - 1] >> 32) != cube) ns[cube] = j;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += SBLOCK) {
+            const unsigned long long k = K[j];
+            if (k == ~0ull) continue;
+            const unsigned cube = (unsigned)(k >> 32);
+            const bool last = j + 1 >= n || K[j + 1] == ~0ull || (unsigned)(K[j + 1] >> 32) != cube;
+            if (last) nc[cube] = j + 1 - ns[cube];
+        }
+        __syncthreads();
+        // inputs of the voxel filters of the valid cubes: old points, then the new ones
+        const int *ts = B.tab_start[type][cur] + (long long)s * LNUM, *tc = B.tab_cnt[type][cur] + (long long)s * LNUM;
+        const long long vcap = (long long)dims.cap[type] + dims.stack_cap[type];
+        int *voff = B.vin_off[type] + (long long)s * MAXVALID, *vcnt = B.vin_cnt[type] + (long long)s * MAXVALID;
+        if (threadIdx.x == 0) {
+            int acc = 0;
+            for (int k = 0; k < nvalid; ++k) {
+                const int c = G.valid[k];
+                s_voff[k] = acc;
+                voff[k] = acc;
+                vcnt[k] = tc[c] + nc[c];
+                acc += tc[c] + nc[c];
+            }
+            s_voff[nvalid] = acc;
+        }
+        __syncthreads();
+        const float4 *pool = B.pool[type][cur] + (long long)s * dims.cap[type];
+        float4 *vin = B.vin[type] + (long long)s * vcap;
+        for (int k = wave; k < nvalid; k += SWAVES) {
+            const int c = G.valid[k], o = s_voff[k], oc = tc[c], st0 = ts[c], nn = nc[c], n0 = ns[c];
+            for (int i = lane; i < oc; i += 64) vin[o + i] = pool[st0 + i];
+            for (int i = lane; i < nn; i += 64) vin[o + oc + i] = newq[n0 + i];
+        }
+        __syncthreads();
+    }
+}
+
+// downSizeFilterCorner / downSizeFilterSurf over one valid cube (LM:1060-1078)
+__global__ __launch_bounds__(SBLOCK) void lm_filter_kernel(const SegState *__restrict__ st, PipeDims dims, PipeBufs B,
+                                                           int *__restrict__ status)
+{
+    extern __shared__ unsigned long long dyn_lds[];
+    __shared__ BlockShared S;
+    __shared__ int s_cnt;
+    const int k = blockIdx.x, s = blockIdx.y >> 1, type = blockIdx.y & 1;
+    const SegState &G = st[s];
+    if (!G.active || k >= G.nvalid) return;
+    const long long vcap = (long long)dims.cap[type] + dims.stack_cap[type];
+    const int off = B.vin_off[type][(long long)s * MAXVALID + k], n = B.vin_cnt[type][(long long)s * MAXVALID + k];
+    if (threadIdx.x == 0) {
+        s_cnt = 0;
+        S.overflow = 0;
+    }
+    __syncthreads();
+    block_voxel_grid(S, B.vin[type] + (long long)s * vcap + off, n, type == 0 ? 0.2f : 0.4f,
+                     B.vout[type] + (long long)s * vcap + off, n, &s_cnt, dyn_lds,
+                     B.vkeys[type] + 2 * ((long long)s * vcap + off), 2 * max(n, 1));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        B.vout_cnt[type][(long long)s * MAXVALID + k] = s_cnt;
+        if (S.overflow) atomicOr(status, 4);
+    }
+}
+
+// writes the next pool compactly: filtered valid cubes, the others as old ++ new
+__global__ __launch_bounds__(SBLOCK) void lm_rebuild_kernel(SegState *__restrict__ st, PipeDims dims, PipeBufs B,
+                                                            int *__restrict__ status)
+{
+    __shared__ short kmap[LNUM];
+    __shared__ int s_part[SBLOCK];
+    __shared__ int s_total;
+    const int s = blockIdx.x >> 1, type = blockIdx.x & 1;
+    const SegState &G = st[s];
+    if (!G.active) return;
+    const int cur = G.cur, nxt = cur ^ 1;
+    const int *ts = B.tab_start[type][cur] + (long long)s * LNUM, *tc = B.tab_cnt[type][cur] + (long long)s * LNUM;
+    int *ts2 = B.tab_start[type][nxt] + (long long)s * LNUM, *tc2 = B.tab_cnt[type][nxt] + (long long)s * LNUM;
+    const int *ns = B.new_start[type] + (long long)s * LNUM, *nc = B.new_cnt[type] + (long long)s * LNUM;
+    const long long vcap = (long long)dims.cap[type] + dims.stack_cap[type];
+    const int *voff = B.vin_off[type] + (long long)s * MAXVALID, *vocnt = B.vout_cnt[type] + (long long)s * MAXVALID;
+    for (int c = threadIdx.x; c < LNUM; c += SBLOCK) kmap[c] = -1;
+    __syncthreads();
+    if (threadIdx.x < G.nvalid) kmap[G.valid[threadIdx.x]] = (short)threadIdx.x;
+    __syncthreads();
+    // exclusive scan of the final counts over the cubes: contiguous chunk per thread
+    constexpr int PER = (LNUM + SBLOCK - 1) / SBLOCK;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int c = threadIdx.x * PER + u;
+        int f = 0;
+        if (c < LNUM) f = kmap[c] >= 0 ? vocnt[kmap[c]] : tc[c] + nc[c];
+        loc[u] = f;
+        sum += f;
+    }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < SBLOCK; ++i) {
+            const int v = s_part[i];
+            s_part[i] = acc;
+            acc += v;
+        }
+        s_total = acc;
+    }
+    __syncthreads();
+    if (s_total > dims.cap[type]) {
+        if (threadIdx.x == 0) atomicOr(status, 8);  // pool capacity
+        return;
+    }
+    int run = s_part[threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int c = threadIdx.x * PER + u;
+        if (c < LNUM) {
+            ts2[c] = run;
+            tc2[c] = loc[u];
+            run += loc[u];
+        }
+    }
+    __syncthreads();
+    const float4 *pool = B.pool[type][cur] + (long long)s * dims.cap[type];
+    float4 *pool2 = B.pool[type][nxt] + (long long)s * dims.cap[type];
+    const float4 *newq = B.newq[type] + (long long)s * dims.stack_cap[type];
+    const float4 *vout = B.vout[type] + (long long)s * vcap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < LNUM; c += SWAVES) {
+        const int cn = tc2[c];
+        if (cn == 0) continue;
+        const int o = ts2[c];
+        const int k = kmap[c];
+        if (k >= 0) {
+            const int vo = voff[k];
+            for (int i = lane; i < cn; i += 64) pool2[o + i] = vout[vo + i];
+        } else {
+            const int oc = tc[c], st0 = ts[c], n0 = ns[c];
+            for (int i = lane; i < oc; i += 64) pool2[o + i] = pool[st0 + i];
+            for (int i = lane; i < cn - oc; i += 64) pool2[o + oc + i] = newq[n0 + i];
+        }
+    }
+}
+
+__global__ void lm_flip_kernel(SegState *__restrict__ st, int nseg)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nseg && st[s].active) st[s].cur ^= 1;
+}
+
+}  // namespace gpscal
+
+using namespace gpscal;
+
+extern "C" int gpscal_loam_run_batched(gpscal_ctx *ctx, int nseg, const float *xyz, const int *sweep_off,
+                                       const int *seg_sweep_off, const double *stamps, float *lo_sum_out,
+                                       float *lm_aft_out, float *tm_mapped_out, double *track_xyzt, int *lm_iters_out,
+                                       int corner_pool_cap, int surf_pool_cap)
+{
+    if (!ctx || nseg < 1 || !xyz || !sweep_off || !seg_sweep_off || !stamps || !track_xyzt)
+        return fail(ctx, GPSCAL_EINVAL, "gpscal_loam_run_batched: bad argument");
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    const int nsw = seg_sweep_off[nseg] - seg_sweep_off[0];
+    if (nsw < 1 || seg_sweep_off[0] != 0) return fail(ctx, GPSCAL_EINVAL, "gpscal_loam_run_batched: bad segment offsets");
+    int tmax = 0;
+    for (int s = 0; s < nseg; ++s) {
+        if (seg_sweep_off[s + 1] < seg_sweep_off[s]) return fail(ctx, GPSCAL_EINVAL, "gpscal_loam_run_batched: bad segment offsets");
+        tmax = std::max(tmax, seg_sweep_off[s + 1] - seg_sweep_off[s]);
+    }
+    const size_t npts = (size_t)std::max(sweep_off[nsw], 1);
+    hipStream_t q = ctx->stream;
+
+    // ---- scanRegistration of every sweep
+    InArg<float> a_xyz;
+    InArg<double> a_stamps;
+    GPSCAL_HIP(ctx, a_xyz.bind(ctx, xyz, npts * 3));
+    GPSCAL_HIP(ctx, a_stamps.bind(ctx, stamps, (size_t)nsw));
+    DevBuf<float4> d_full, d_sharp, d_lsharp, d_flat, d_lflat;
+    DevBuf<int> d_counts;
+    GPSCAL_HIP(ctx, d_full.alloc(npts));
+    GPSCAL_HIP(ctx, d_sharp.alloc((size_t)nsw * 1536));
+    GPSCAL_HIP(ctx, d_lsharp.alloc((size_t)nsw * 1920));
+    GPSCAL_HIP(ctx, d_flat.alloc((size_t)nsw * 3072));
+    GPSCAL_HIP(ctx, d_lflat.alloc(npts));
+    GPSCAL_HIP(ctx, d_counts.alloc((size_t)nsw * 5));
+    int sr_status = 0;
+    int rc = scan_registration_device(ctx, nsw, sweep_off, sweep_off, a_xyz.dev, d_full.p, d_sharp.p, d_lsharp.p,
+                                      d_flat.p, d_lflat.p, d_counts.p, &sr_status);
+    if (rc) return rc;
+    if (sr_status & 2) return fail(ctx, GPSCAL_ESIZE, "gpscal_loam_run_batched: a sweep has more than 60000 ring points");
+    if (sr_status & 1) return fail(ctx, GPSCAL_ERANGE, "gpscal_loam_run_batched: less-flat capacity exceeded (sweep with missing rings)");
+    std::vector<int> cnt((size_t)nsw * 5);
+    GPSCAL_HIP(ctx, hipMemcpyAsync(cnt.data(), d_counts.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, q));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(q));
+    d_full.release();
+    int max_ls = 1, max_lf = 1;
+    for (int g = 0; g < nsw; ++g) {
+        max_ls = std::max(max_ls, cnt[5 * g + 2]);
+        max_lf = std::max(max_lf, cnt[5 * g + 4]);
+    }
+
+    // ---- state and map buffers
+    PipeDims dims;
+    dims.nseg = nseg;
+    dims.cap[0] = corner_pool_cap > 0 ? corner_pool_cap : 1 << 18;
+    dims.cap[1] = surf_pool_cap > 0 ? surf_pool_cap : 1 << 20;
+    dims.stack_cap[0] = max_ls;
+    dims.stack_cap[1] = max_lf;
+    for (int t = 0; t < 2; ++t) {
+        int np2 = 1;
+        while (np2 < dims.stack_cap[t]) np2 <<= 1;
+        dims.key_cap[t] = np2;
+    }
+    DevBuf<SegState> d_state;
+    GPSCAL_HIP(ctx, d_state.alloc(nseg));
+    GPSCAL_HIP(ctx, hipMemsetAsync(d_state.p, 0, sizeof(SegState) * nseg, q));
+    PipeBufs B;
+    DevBuf<float4> b_pool[2][2], b_frommap[2], b_stack2[2], b_stack[2], b_newq[2], b_vin[2], b_vout[2];
+    DevBuf<int> b_ts[2][2], b_tc[2][2], b_ns[2], b_nc[2], b_voff[2], b_vcnt[2], b_vocnt[2];
+    DevBuf<unsigned long long> b_keys[2], b_vkeys[2];
+    for (int t = 0; t < 2; ++t) {
+        const size_t vcap = (size_t)dims.cap[t] + dims.stack_cap[t];
+        for (int k = 0; k < 2; ++k) {
+            GPSCAL_HIP(ctx, b_pool[t][k].alloc((size_t)nseg * dims.cap[t]));
+            GPSCAL_HIP(ctx, b_ts[t][k].alloc((size_t)nseg * LNUM));
+            GPSCAL_HIP(ctx, b_tc[t][k].alloc((size_t)nseg * LNUM));
+            GPSCAL_HIP(ctx, hipMemsetAsync(b_ts[t][k].p, 0, sizeof(int) * (size_t)nseg * LNUM, q));
+            GPSCAL_HIP(ctx, hipMemsetAsync(b_tc[t][k].p, 0, sizeof(int) * (size_t)nseg * LNUM, q));
+            B.pool[t][k] = b_pool[t][k].p;
+            B.tab_start[t][k] = b_ts[t][k].p;
+            B.tab_cnt[t][k] = b_tc[t][k].p;
+        }
+        GPSCAL_HIP(ctx, b_frommap[t].alloc((size_t)nseg * dims.cap[t]));
+        GPSCAL_HIP(ctx, b_stack2[t].alloc((size_t)nseg * dims.stack_cap[t]));
+        GPSCAL_HIP(ctx, b_stack[t].alloc((size_t)nseg * dims.stack_cap[t]));
+        GPSCAL_HIP(ctx, b_newq[t].alloc((size_t)nseg * dims.stack_cap[t]));
+        GPSCAL_HIP(ctx, b_ns[t].alloc((size_t)nseg * LNUM));
+        GPSCAL_HIP(ctx, b_nc[t].alloc((size_t)nseg * LNUM));
+        GPSCAL_HIP(ctx, b_vin[t].alloc((size_t)nseg * vcap));
+        GPSCAL_HIP(ctx, b_vout[t].alloc((size_t)nseg * vcap));
+        GPSCAL_HIP(ctx, b_voff[t].alloc((size_t)nseg * MAXVALID));
+        GPSCAL_HIP(ctx, b_vcnt[t].alloc((size_t)nseg * MAXVALID));
+        GPSCAL_HIP(ctx, b_vocnt[t].alloc((size_t)nseg * MAXVALID));
+        GPSCAL_HIP(ctx, b_keys[t].alloc((size_t)nseg * dims.key_cap[t]));
+        GPSCAL_HIP(ctx, b_vkeys[t].alloc((size_t)nseg * 2 * vcap));
+        B.frommap[t] = b_frommap[t].p;
+        B.stack2[t] = b_stack2[t].p;
+        B.stack[t] = b_stack[t].p;
+        B.newq[t] = b_newq[t].p;
+        B.new_start[t] = b_ns[t].p;
+        B.new_cnt[t] = b_nc[t].p;
+        B.vin[t] = b_vin[t].p;
+        B.vout[t] = b_vout[t].p;
+        B.vin_off[t] = b_voff[t].p;
+        B.vin_cnt[t] = b_vcnt[t].p;
+        B.vout_cnt[t] = b_vocnt[t].p;
+        B.keys[t] = b_keys[t].p;
+        B.vkeys[t] = b_vkeys[t].p;
+    }
+    // last clouds (double buffered), packed map / stack clouds, per-step scalars
+    DevBuf<float4> d_clast[2], d_slast[2], d_cmap, d_smap, d_cstack, d_sstack;
+    for (int k = 0; k < 2; ++k) {
+        GPSCAL_HIP(ctx, d_clast[k].alloc((size_t)nseg * max_ls));
+        GPSCAL_HIP(ctx, d_slast[k].alloc((size_t)nseg * max_lf));
+    }
+    GPSCAL_HIP(ctx, d_cmap.alloc((size_t)nseg * dims.cap[0]));
+    GPSCAL_HIP(ctx, d_smap.alloc((size_t)nseg * dims.cap[1]));
+    GPSCAL_HIP(ctx, d_cstack.alloc((size_t)nseg * dims.stack_cap[0]));
+    GPSCAL_HIP(ctx, d_sstack.alloc((size_t)nseg * dims.stack_cap[1]));
+    DevBuf<PostDesc> d_post;
+    DevBuf<PrepDesc> d_prep;
+    DevBuf<PackDesc> d_pack;
+    DevBuf<int> d_rows, d_sizes, d_status, d_iters, d_nsel;
+    DevBuf<float> d_tr, d_tr2;
+    GPSCAL_HIP(ctx, d_post.alloc(nseg));
+    GPSCAL_HIP(ctx, d_prep.alloc(nseg));
+    GPSCAL_HIP(ctx, d_pack.alloc(nseg));
+    GPSCAL_HIP(ctx, d_rows.alloc(nseg));
+    GPSCAL_HIP(ctx, d_sizes.alloc((size_t)nseg * 4));
+    GPSCAL_HIP(ctx, d_status.alloc(1));
+    GPSCAL_HIP(ctx, d_iters.alloc(nseg));
+    GPSCAL_HIP(ctx, d_nsel.alloc(nseg));
+    GPSCAL_HIP(ctx, d_tr.alloc((size_t)nseg * 6));
+    GPSCAL_HIP(ctx, d_tr2.alloc((size_t)nseg * 6));
+    GPSCAL_HIP(ctx, hipMemsetAsync(d_status.p, 0, sizeof(int), q));
+    OutArg<float> o_lo, o_lm, o_tm;
+    OutArg<double> o_track;
+    OutArg<int> o_it;
+    GPSCAL_HIP(ctx, o_lo.bind(ctx, lo_sum_out, lo_sum_out ? (size_t)nsw * 6 : 0));
+    GPSCAL_HIP(ctx, o_lm.bind(ctx, lm_aft_out, lm_aft_out ? (size_t)nsw * 6 : 0));
+    GPSCAL_HIP(ctx, o_tm.bind(ctx, tm_mapped_out, tm_mapped_out ? (size_t)nsw * 6 : 0));
+    GPSCAL_HIP(ctx, o_track.bind(ctx, track_xyzt, (size_t)nsw * 4));
+    GPSCAL_HIP(ctx, o_it.bind(ctx, lm_iters_out, lm_iters_out ? (size_t)nsw : 0));
+    // rows no node writes stay NaN / -1 (sweep 0 of a segment; sweeps without a mapping cycle)
+    if (o_lm.dev) GPSCAL_HIP(ctx, hipMemsetAsync(o_lm.dev, 0xff, sizeof(float) * (size_t)nsw * 6, q));
+    if (o_tm.dev) GPSCAL_HIP(ctx, hipMemsetAsync(o_tm.dev, 0xff, sizeof(float) * (size_t)nsw * 6, q));
+    if (o_it.dev) GPSCAL_HIP(ctx, hipMemsetAsync(o_it.dev, 0xff, sizeof(int) * (size_t)nsw, q));
+    GPSCAL_HIP(ctx, hipMemsetAsync(o_track.dev, 0xff, sizeof(double) * (size_t)nsw * 4, q));
+
+    const size_t lds_keys = sizeof(unsigned long long) * LDS_KEYS;
+    std::vector<PostDesc> hpost(nseg);
+    std::vector<PrepDesc> hprep(nseg);
+    std::vector<PackDesc> hpack(nseg);
+    std::vector<SweepDesc> hsw(nseg);
+    std::vector<MapDesc> hmap(nseg);
+    std::vector<int> hrows(nseg), hsizes((size_t)nseg * 4);
+    std::vector<long long> coff(nseg + 1), soff(nseg + 1), coff_new(nseg + 1), soff_new(nseg + 1), cmoff(nseg + 1),
+        smoff(nseg + 1);
+    int lastbuf = 0;
+    for (int s = 0; s <= nseg; ++s) coff[s] = soff[s] = 0;
+    SegState *S = d_state.p;
+    // the odometry kernel reads / writes transform and transformSum through flat arrays
+    auto state_f = [&](size_t member_off) { return reinterpret_cast<float *>(reinterpret_cast<char *>(S) + member_off); };
+    (void)state_f;
+
+    for (int t = 0; t < tmax; ++t) {
+        const int newbuf = lastbuf ^ 1;
+        // ---- laserOdometry (LO:565-1085); nothing to match against at t = 0, and at t = 1 the
+        // reference's stale counters (LO:520-521) skip the loop as well
+        coff_new[0] = soff_new[0] = 0;
+        for (int s = 0; s < nseg; ++s) {
+            const int ns_s = seg_sweep_off[s + 1] - seg_sweep_off[s];
+            const bool act = t < ns_s;
+            const int g = seg_sweep_off[s] + t;
+            hrows[s] = act ? g : -1;
+            PostDesc &P = hpost[s];
+            P.row = act ? g : -1;
+            P.nc = act ? cnt[5 * g + 2] : 0;
+            P.ns = act ? cnt[5 * g + 4] : 0;
+            P.src_c = (long long)g * 1920;
+            P.src_s = act ? sweep_off[g] : 0;
+            P.dst_c = coff_new[s];
+            P.dst_s = soff_new[s];
+            P.identity = t == 0;
+            coff_new[s + 1] = coff_new[s] + P.nc;
+            soff_new[s + 1] = soff_new[s] + P.ns;
+            SweepDesc &D = hsw[s];
+            D.sharp_off = (long long)g * 1536;
+            D.flat_off = (long long)g * 3072;
+            D.clast_off = coff[s];
+            D.slast_off = soff[s];
+            D.nc = act ? cnt[5 * g + 1] : 0;
+            D.ns = act ? cnt[5 * g + 3] : 0;
+            const bool matchable = act && t >= 2;
+            D.mc = matchable ? (int)(coff[s + 1] - coff[s]) : 0;
+            D.ms = matchable ? (int)(soff[s + 1] - soff[s]) : 0;
+        }
+        GPSCAL_HIP(ctx, hipMemcpyAsync(d_rows.p, hrows.data(), sizeof(int) * nseg, hipMemcpyHostToDevice, q));
+        GPSCAL_HIP(ctx, hipMemcpyAsync(d_post.p, hpost.data(), sizeof(PostDesc) * nseg, hipMemcpyHostToDevice, q));
+        if (t >= 1) {
+            // transform / transformSum live in SegState; the kernel takes flat [nseg][6] arrays
+            GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr.p, 24, &S[0].lo_tr[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
+            GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr2.p, 24, &S[0].lo_sum[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
+            rc = loam_odometry_device(ctx, nseg, hsw.data(), d_sharp.p, d_flat.p, d_clast[lastbuf].p, d_slast[lastbuf].p,
+                                      coff.data(), soff.data(), d_tr.p, d_tr.p, nullptr, nullptr, d_tr2.p, d_tr2.p);
+            if (rc) return rc;
+            GPSCAL_HIP(ctx, hipMemcpy2DAsync(&S[0].lo_tr[0], sizeof(SegState), d_tr.p, 24, 24, nseg, hipMemcpyDeviceToDevice, q));
+            GPSCAL_HIP(ctx, hipMemcpy2DAsync(&S[0].lo_sum[0], sizeof(SegState), d_tr2.p, 24, 24, nseg, hipMemcpyDeviceToDevice, q));
+        }
+        {
+            const int gx = std::max(1, std::min(div_up(std::max(max_ls + max_lf, 1), 256), 64));
+            hipLaunchKernelGGL(lo_post_kernel, dim3(gx, nseg), dim3(256), 0, q, d_post.p, S, d_lsharp.p, d_lflat.p,
+                               d_clast[newbuf].p, d_slast[newbuf].p, o_lo.dev);
+            GPSCAL_HIP(ctx, hipGetLastError());
+        }
+        lastbuf = newbuf;
+        coff = coff_new;
+        soff = soff_new;
+        if (t == 0) continue;
+        // ---- transformMaintenance on the odometry of this sweep
+        hipLaunchKernelGGL(tm_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, d_rows.p, a_stamps.dev, nseg, o_tm.dev,
+                           o_track.dev);
+        GPSCAL_HIP(ctx, hipGetLastError());
+        if ((t & 1) == 0) continue;  // skipFrameNum = 1: laserMapping sees every second sweep (LO:1099-1127)
+        // ---- laserMapping
+        for (int s = 0; s < nseg; ++s) {
+            PrepDesc &P = hprep[s];
+            P.clast_off = coff[s];
+            P.slast_off = soff[s];
+            P.nc = (int)(coff[s + 1] - coff[s]);
+            P.ns = (int)(soff[s + 1] - soff[s]);
+            P.active = hrows[s] >= 0;
+            P.pad = 0;
+        }
+        GPSCAL_HIP(ctx, hipMemcpyAsync(d_prep.p, hprep.data(), sizeof(PrepDesc) * nseg, hipMemcpyHostToDevice, q));
+        hipLaunchKernelGGL(lm_prepare_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, d_prep.p, S, dims, B,
+                           d_clast[lastbuf].p, d_slast[lastbuf].p, d_sizes.p, d_status.p);
+        GPSCAL_HIP(ctx, hipGetLastError());
+        GPSCAL_HIP(ctx, hipMemcpyAsync(hsizes.data(), d_sizes.p, sizeof(int) * hsizes.size(), hipMemcpyDeviceToHost, q));
+        GPSCAL_HIP(ctx, hipStreamSynchronize(q));
+        cmoff[0] = smoff[0] = 0;
+        long long cso = 0, sso = 0;
+        int nmax = 1;
+        for (int s = 0; s < nseg; ++s) {
+            const int mc = hsizes[4 * s], ms = hsizes[4 * s + 1], nc = hsizes[4 * s + 2], ns = hsizes[4 * s + 3];
+            PackDesc &P = hpack[s];
+            P.dst[0] = cmoff[s]; P.dst[1] = smoff[s]; P.dst[2] = cso; P.dst[3] = sso;
+            P.n[0] = mc; P.n[1] = ms; P.n[2] = nc; P.n[3] = ns;
+            MapDesc &M = hmap[s];
+            M.cmap_off = cmoff[s]; M.smap_off = smoff[s]; M.cstack_off = cso; M.sstack_off = sso;
+            M.mc = mc; M.ms = ms; M.nc = nc; M.ns = ns;
+            cmoff[s + 1] = cmoff[s] + mc;
+            smoff[s + 1] = smoff[s] + ms;
+            cso += nc;
+            sso += ns;
+            nmax = std::max(nmax, std::max(std::max(mc, ms), std::max(nc, ns)));
+        }
+        GPSCAL_HIP(ctx, hipMemcpyAsync(d_pack.p, hpack.data(), sizeof(PackDesc) * nseg, hipMemcpyHostToDevice, q));
+        hipLaunchKernelGGL(lm_pack_kernel, dim3(std::max(1, std::min(div_up(nmax, 256), 128)), nseg), dim3(256), 0, q,
+                           d_pack.p, dims, B, d_cmap.p, d_smap.p, d_cstack.p, d_sstack.p);
+        GPSCAL_HIP(ctx, hipGetLastError());
+        GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr.p, 24, &S[0].tTobe[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
+        rc = loam_mapping_device(ctx, nseg, hmap.data(), d_cstack.p, d_sstack.p, d_cmap.p, d_smap.p, cmoff.data(),
+                                 smoff.data(), d_tr.p, d_tr2.p, d_iters.p, d_nsel.p);
+        if (rc) return rc;
+        hipLaunchKernelGGL(lm_insert_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, S, dims, B, d_sizes.p, d_tr2.p,
+                           d_iters.p, d_rows.p, o_lm.dev, o_it.dev, d_status.p);
+        hipLaunchKernelGGL(lm_filter_kernel, dim3(MAXVALID, nseg * 2), dim3(SBLOCK), lds_keys, q, S, dims, B, d_status.p);
+        hipLaunchKernelGGL(lm_rebuild_kernel, dim3(nseg * 2), dim3(SBLOCK), 0, q, S, dims, B, d_status.p);
+        hipLaunchKernelGGL(lm_flip_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, nseg);
+        GPSCAL_HIP(ctx, hipGetLastError());
+    }
+    int st = 0;
+    GPSCAL_HIP(ctx, hipMemcpyAsync(&st, d_status.p, sizeof(int), hipMemcpyDeviceToHost, q));
+    bool sync = true;
+    GPSCAL_HIP(ctx, o_lo.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, o_lm.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, o_tm.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, o_track.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, o_it.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(q));
+    if (st & 8) return fail(ctx, GPSCAL_ENOMEM, "gpscal_loam_run_batched: map pool capacity exceeded (raise corner_pool_cap / surf_pool_cap)");
+    if (st & 4) return fail(ctx, GPSCAL_ERANGE, "gpscal_loam_run_batched: internal scratch capacity exceeded");
+    return GPSCAL_OK;
+}

@@ -379,3 +379,24 @@ def raw_sweep(world, pos=(0.0, 0.0), yaw=0.0, vel=(0.0, 0.0), yaw_rate=0.0, seed
     if nan_every > 0:
         pts[::nan_every] = np.nan
     return pts
+
+
+def drive(world, nsweeps, seed=0, speed=8.0, n_az=900, start=(0.0, 0.0), yaw0=0.0, wiggle=0.02, period=0.1):
+    """Raw sweeps of a drive along the street: constant-ish speed with a slow sinusoidal heading
+    wiggle.  Returns (list of [n,3] float32 sweeps, stamps[nsweeps], truth[nsweeps,3] = x, y, yaw at
+    the START of each sweep)."""
+    rng = np.random.default_rng(seed)
+    x, y, yaw = float(start[0]), float(start[1]), float(yaw0)
+    sweeps, truth = [], []
+    for t in range(nsweeps):
+        v = speed * (1.0 + 0.1 * math.sin(0.07 * t))
+        yaw_rate = wiggle * math.cos(0.05 * t)
+        vel = (v * math.cos(yaw), v * math.sin(yaw))
+        truth.append((x, y, yaw))
+        sweeps.append(raw_sweep(world, pos=(x, y), yaw=yaw, vel=vel, yaw_rate=yaw_rate, seed=int(rng.integers(1 << 30)),
+                                n_az=n_az, period=period))
+        x += vel[0] * period
+        y += vel[1] * period
+        yaw += yaw_rate * period
+    stamps = 1494650700.0 + period * np.arange(nsweeps)
+    return sweeps, stamps, np.array(truth)

@@ -280,6 +280,31 @@ int gpscal_scan_registration_batched(gpscal_ctx *ctx, int nsweeps,
 int gpscal_voxel_grid_batched(gpscal_ctx *ctx, int nclouds, const float *pts_xyzi,
                               const int *off, float leaf, float *out_xyzi, int *counts);
 
+/* ------------------------------------------------------ the LOAM node chain */
+/* Replaces the four LOAM nodes of launch/loam_velodyne.launch -- scanRegistration,
+ * laserOdometry, laserMapping, transformMaintenance -- for nseg pre-cut SLAM segments run in
+ * lock step on the device: per sweep, scanRegistration's features (SR:238-674), laserOdometry's
+ * state machine and loop (LO:495-1124), every second sweep laserMapping's cycle (LM:420-1148:
+ * transformAssociateToMap, the 21x11x21 cube ring with its shifts, the field-of-view cube list,
+ * the stack / cube voxel filters, the optimisation loop, transformUpdate), and
+ * transformMaintenance's integration and height compensation (TM:113-157, 178-337) that
+ * produces the /true_odometry_to_init samples input_data collects into the SLAM track
+ * (ID:266-444).  Schedule: each node finishes a sweep before the next one arrives (the
+ * reference's bag playback rate guarantees this); no IMU.
+ * xyz = packed float[3] raw points, sweep_off = nsweeps+1 point offsets over ALL sweeps,
+ * seg_sweep_off = nseg+1 sweep-index offsets (seg_sweep_off[0] = 0), stamps = one per sweep.
+ * Outputs, one row per sweep (optional unless noted): lo_sum = laserOdometry's transformSum,
+ * lm_aft = transformAftMapped (NaN where laserMapping did not run), tm_mapped =
+ * transformMaintenance's pose, track_xyzt (required) = {x, y, HEIGHT, stamp} (NaN for the first
+ * sweep of a segment, which publishes no odometry, LO:519-562), lm_iters = mapping iterations
+ * (-1 where it did not run).  *_pool_cap = map points kept per segment (0 = 262144 / 1048576);
+ * GPSCAL_ENOMEM when a map outgrows them. */
+int gpscal_loam_run_batched(gpscal_ctx *ctx, int nseg, const float *xyz,
+                            const int *sweep_off, const int *seg_sweep_off,
+                            const double *stamps, float *lo_sum, float *lm_aft,
+                            float *tm_mapped, double *track_xyzt, int *lm_iters,
+                            int corner_pool_cap, int surf_pool_cap);
+
 /* ------------------------------------------------------------- multi-GPU */
 /* New (no reference counterpart): the one exchange of the sharded pipeline,
  * an RCCL all-gather of per-segment pose chains / fit results over xGMI

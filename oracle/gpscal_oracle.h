@@ -180,6 +180,18 @@ int orc_sr_extract(const float *xyz, int n_in, float *full, int *n_full, float *
  * (more than INT_MAX cells) and copy the input. */
 int orc_voxel_grid(const float *pts_xyzi, int n, float leaf, float *out_xyzi, int *n_out);
 
+/* ------------------------------------------------------- the four LOAM nodes */
+/* transformAssociateToMap (laserMapping.cpp:116-203 == transformMaintenance.cpp:178-265). */
+void orc_assoc_to_map(const float sum[6], const float bef[6], const float aft[6], float out[6]);
+/* scanRegistration -> laserOdometry -> laserMapping -> transformMaintenance in lock step
+ * over the raw sweeps of one segment (see pipeline_oracle.c for the schedule).  Per sweep t:
+ * lo_sum = laserOdometry's transformSum, lm_aft = transformAftMapped (NaN when laserMapping
+ * did not run), tm_mapped = transformMaintenance's integrated pose, track = the
+ * /true_odometry_to_init sample {x, y, HEIGHT, stamp} (NaN for sweep 0), lm_iters = mapping
+ * iterations (-1 when it did not run).  Arrays are nsweeps x 6 / x 4 / x 1. */
+int orc_loam_run(const float *xyz, const int *sweep_off, int nsweeps, const double *stamps, float *lo_sum,
+                 float *lm_aft, float *tm_mapped, double *track, int *lm_iters);
+
 #ifdef __cplusplus
 }
 #endif

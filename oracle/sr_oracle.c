@@ -13,10 +13,11 @@
  *
  * PARITY UNPINNED: PCL is absent and the reference ships no fixtures for this path.
  * Choices made where the C++ is toolchain dependent:
- *   - unqualified sqrt()/atan() on float arguments are the double functions (the global
- *     namespace of <cmath> on the GCC 5 era toolchains the install scripts target);
- *   - std::atan2(float,float) is restated as the correctly rounded float of the double
- *     atan2 (what glibc's atan2f returns except in rare 1-ulp cases);
+ *   - common.h:31 says `using namespace std;`, so unqualified sqrt / atan / atan2 / fabs on
+ *     float arguments are the float overloads (sqrtf, atanf, atan2f);
+ *   - atanf / atan2f are restated as the correctly rounded float of the double function
+ *     (what glibc returns except in rare 1-ulp cases), so that this file and the HIP kernel,
+ *     which have different libms, agree bit for bit;
  *   - the global work arrays (cloudCurvature, cloudSortInd, cloudNeighborPicked, cloudLabel)
  *     are zero outside [5, cloudSize-5), i.e. the state of a first sweep;
  *   - std::sort in VoxelGrid leaves the order of equal cell ids unspecified; the
@@ -31,6 +32,7 @@
 #define N_SCANS 16
 
 static float atan2_f(float y, float x) { return (float)atan2((double)y, (double)x); }
+static float atan_f(float x) { return (float)atan((double)x); }
 
 static int ring_of(int roundedAngle)
 {
@@ -158,7 +160,7 @@ int orc_sr_extract(const float *xyz, int n_in, float *full, int *n_full, float *
     int ring_cnt[N_SCANS] = {0};
     for (int i = 0; i < cloudSize; ++i) {
         float px = in[3 * i + 1], py = in[3 * i + 2], pz = in[3 * i]; /* SR:295-297 */
-        float angle = (float)(atan((double)py / sqrt((double)(px * px + pz * pz))) * 180 / M_PI);
+        float angle = (float)((double)(atan_f(py / sqrtf(px * px + pz * pz)) * 180) / M_PI);
         int roundedAngle = (int)(angle + (angle < 0.0 ? -0.5 : +0.5));
         int scanID = ring_of(roundedAngle);
         ring[i] = scanID;
@@ -230,19 +232,19 @@ int orc_sr_extract(const float *xyz, int n_in, float *full, int *n_full, float *
         float dX = P(i + 1, 0) - P(i, 0), dY = P(i + 1, 1) - P(i, 1), dZ = P(i + 1, 2) - P(i, 2);
         float diff = dX * dX + dY * dY + dZ * dZ;
         if ((double)diff > 0.1) {
-            float depth1 = (float)sqrt((double)(P(i, 0) * P(i, 0) + P(i, 1) * P(i, 1) + P(i, 2) * P(i, 2)));
-            float depth2 = (float)sqrt((double)(P(i + 1, 0) * P(i + 1, 0) + P(i + 1, 1) * P(i + 1, 1) + P(i + 1, 2) * P(i + 1, 2)));
+            float depth1 = sqrtf(P(i, 0) * P(i, 0) + P(i, 1) * P(i, 1) + P(i, 2) * P(i, 2));
+            float depth2 = sqrtf(P(i + 1, 0) * P(i + 1, 0) + P(i + 1, 1) * P(i + 1, 1) + P(i + 1, 2) * P(i + 1, 2));
             if (depth1 > depth2) {
                 dX = P(i + 1, 0) - P(i, 0) * depth2 / depth1;
                 dY = P(i + 1, 1) - P(i, 1) * depth2 / depth1;
                 dZ = P(i + 1, 2) - P(i, 2) * depth2 / depth1;
-                if (sqrt((double)(dX * dX + dY * dY + dZ * dZ)) / (double)depth2 < 0.1)
+                if ((double)(sqrtf(dX * dX + dY * dY + dZ * dZ) / depth2) < 0.1)
                     for (int l = -5; l <= 0; ++l) picked[i + l] = 1;
             } else {
                 dX = P(i + 1, 0) * depth1 / depth2 - P(i, 0);
                 dY = P(i + 1, 1) * depth1 / depth2 - P(i, 1);
                 dZ = P(i + 1, 2) * depth1 / depth2 - P(i, 2);
-                if (sqrt((double)(dX * dX + dY * dY + dZ * dZ)) / (double)depth1 < 0.1)
+                if ((double)(sqrtf(dX * dX + dY * dY + dZ * dZ) / depth1) < 0.1)
                     for (int l = 1; l <= 6; ++l) picked[i + l] = 1;
             }
         }

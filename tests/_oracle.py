@@ -326,3 +326,20 @@ def voxel_grid(pts, leaf):
     no = C.c_int(0)
     rc = lib().orc_voxel_grid(_p(pts, c_fp), len(pts), C.c_float(leaf), _p(out, c_fp), C.byref(no))
     return out[:no.value].copy(), rc
+
+
+def loam_run(sweeps, stamps):
+    """The four LOAM nodes in lock step over a list of raw sweeps [n,3] float32."""
+    ns = len(sweeps)
+    off = np.zeros(ns + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(a) for a in sweeps])
+    xyz = np.ascontiguousarray(np.concatenate(sweeps), dtype=np.float32)
+    stamps = np.ascontiguousarray(stamps, dtype=np.float64)
+    lo = np.zeros((ns, 6), dtype=np.float32)
+    lm = np.zeros((ns, 6), dtype=np.float32)
+    tm = np.zeros((ns, 6), dtype=np.float32)
+    track = np.zeros((ns, 4), dtype=np.float64)
+    iters = np.zeros(ns, dtype=np.int32)
+    lib().orc_loam_run(_p(xyz, c_fp), _p(off, C.POINTER(C.c_int)), ns, _p(stamps, c_dp), _p(lo, c_fp), _p(lm, c_fp),
+                       _p(tm, c_fp), _p(track, c_dp), _p(iters, C.POINTER(C.c_int)))
+    return {"lo_sum": lo, "lm_aft": lm, "tm_mapped": tm, "track": track, "lm_iters": iters}

@@ -4,7 +4,8 @@ VoxelGrid filter against the oracle, on synthetic 16-ring sweeps of a street sce
 Parity bar: ring assignment, ring order, curvature, rejection flags, the per-sector sort and the
 picking are integer / exact-float32 work on identical inputs, so point SELECTION and xyz are
 bit-exact.  The intensity channel carries relTime, which goes through atan2 (device libm vs
-glibc, both evaluated in float64 and rounded to float32): tolerance 2e-6.  Parity unpinned
+glibc, both evaluated in float64 and rounded to float32): tolerance 2e-6.  sqrtf and float division
+are IEEE-exact on both sides (the device build uses no fast-math).  Parity unpinned
 against the reference itself (PCL absent, no fixtures): see oracle/sr_oracle.c."""
 import numpy as np
 import pytest
