@@ -94,6 +94,7 @@ __device__ __forceinline__ long long cell_of(const GridDesc &G, float x, float y
 template <int K>
 struct Best {
     static constexpr bool COOP = false;  // k > 1: per-lane scanning only
+    static constexpr bool WARM_START = true;
     float d[K];
     int i[K];
     __device__ __forceinline__ void init()
@@ -136,6 +137,7 @@ struct Best {
 // winner's position in `sorted` (WARM = the warm-start candidate is still best).
 struct BestQ {
     static constexpr bool COOP = true;  // long runs are scanned by the whole wave
+    static constexpr bool WARM_START = true;  // worst() of a fresh record is a real candidate's distance
     static constexpr unsigned WARM = 0xffffffffu;
     static constexpr unsigned LIST = 0xfffffff0u;  // LIST + j: j-th entry of q0's neighbour list
     unsigned long long key;
@@ -154,6 +156,40 @@ struct BestQ {
         if (k2 < key) {
             key = k2;
             pos = p;
+        }
+    }
+};
+
+// Nearest point whose index lies in [a0,a1) or [b0,b1), other than `closest`, within an initial
+// squared radius: laserOdometry's walks over the adjacent rings of the last sweep (LO:613-677,
+// 769-844) as one filtered search.  Ties go to the candidate the sequential walk meets first:
+// indices above `closest` ascending, then indices below it descending.
+struct BestRing {
+    static constexpr bool COOP = false;
+    static constexpr bool WARM_START = false;  // the bound is a radius, not a candidate
+    float d;
+    int i;
+    unsigned ord;
+    int a0, a1, b0, b1, closest;
+    __device__ __forceinline__ void init(float bound2, int closest_, int a0_, int a1_, int b0_, int b1_)
+    {
+        d = bound2;
+        i = -1;
+        ord = 0u;
+        closest = closest_;
+        a0 = a0_; a1 = a1_; b0 = b0_; b1 = b1_;
+    }
+    __device__ __forceinline__ float worst() const { return d; }
+    __device__ __forceinline__ void consider(float d2, const float4 &c, unsigned)
+    {
+        const int idx = __float_as_int(c.w);
+        const bool in = ((idx >= a0 && idx < a1) || (idx >= b0 && idx < b1)) && idx != closest;
+        if (!in) return;
+        const unsigned o = idx > closest ? (unsigned)(idx - closest) : 0x40000000u + (unsigned)(closest - idx);
+        if (d2 < d || (d2 == d && i >= 0 && o < ord)) {
+            d = d2;
+            i = idx;
+            ord = o;
         }
     }
 };
@@ -295,7 +331,7 @@ __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__res
     int start = 0;
     {
         const float w0 = B.worst();
-        if (w0 < INFINITY) {
+        if (BT::WARM_START && w0 < INFINITY) {
             start = P.nlevels - 1;
             for (int l = P.nlevels - 2; l >= 0; --l) {
                 const float g = P.lv[l].h * 0.999f - P.lv[l].margin;

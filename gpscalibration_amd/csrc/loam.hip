@@ -29,6 +29,7 @@ namespace gpscal {
 constexpr int LBLOCK = 512;
 constexpr int LWAVES = LBLOCK / 64;
 constexpr int LSUMS = 28;  // 21 upper-triangle AtA + 6 AtB + 1 row count
+constexpr int RS = 8;       // ring-walk candidates fetched per step
 
 
 __device__ __forceinline__ float4 lo_to_start(const float *tr, float4 p)
@@ -103,64 +104,88 @@ __device__ __forceinline__ void lo_row(const float *tr, float4 pt, float4 cf, do
     sum[27] += 1.0;
 }
 
-// ---- thread-0 dense helpers on LDS-resident 6x6 systems (float64)
-__device__ void lo_solve_qr6(double *A, double *b, double *x, double *v)
+// ---- thread-0 dense helpers on register-resident 6x6 systems (float64).  Every loop is fully
+// unrolled so that the arrays live in VGPRs: the same code over LDS pointers cost ~100 cycles per
+// access on a single lane and dominated the iteration time.
+__device__ __forceinline__ void lo_solve_qr6(double (&A)[36], double (&b)[6], double (&x)[6])
 {
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
         double nrm = 0;
+#pragma unroll
         for (int i = k; i < 6; ++i) nrm += A[6 * i + k] * A[6 * i + k];
         nrm = sqrt(nrm);
         if (nrm == 0.0) continue;
         const double alpha = A[6 * k + k] > 0 ? -nrm : nrm;
+        double v[6];
+#pragma unroll
         for (int i = 0; i < 6; ++i) v[i] = i >= k ? A[6 * i + k] : 0.0;
         v[k] -= alpha;
         double vv = 0;
+#pragma unroll
         for (int i = k; i < 6; ++i) vv += v[i] * v[i];
         if (vv == 0.0) continue;
+#pragma unroll
         for (int j = k; j < 6; ++j) {
             double d = 0;
+#pragma unroll
             for (int i = k; i < 6; ++i) d += v[i] * A[6 * i + j];
             d = 2 * d / vv;
+#pragma unroll
             for (int i = k; i < 6; ++i) A[6 * i + j] -= d * v[i];
         }
         double d = 0;
+#pragma unroll
         for (int i = k; i < 6; ++i) d += v[i] * b[i];
         d = 2 * d / vv;
+#pragma unroll
         for (int i = k; i < 6; ++i) b[i] -= d * v[i];
     }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = 0.0;
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double acc = b[i];
+#pragma unroll
         for (int j = i + 1; j < 6; ++j) acc -= A[6 * i + j] * x[j];
         x[i] = A[6 * i + i] != 0.0 ? acc / A[6 * i + i] : 0.0;
     }
 }
 
 // eigen-decomposition of the symmetric A (destroyed); Q columns = eigenvectors
-__device__ void lo_eigen_sym6(double *A, double *Q)
+__device__ __forceinline__ void lo_eigen_sym6(double (&A)[36], double (&Q)[36])
 {
+#pragma unroll
     for (int i = 0; i < 36; ++i) Q[i] = (i % 7 == 0) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0;
+#pragma unroll
         for (int p = 0; p < 6; ++p)
+#pragma unroll
             for (int q = p + 1; q < 6; ++q) off += A[6 * p + q] * A[6 * p + q];
         if (off < 1e-300) break;
+#pragma unroll
         for (int p = 0; p < 6; ++p)
+#pragma unroll
             for (int q = p + 1; q < 6; ++q) {
                 const double apq = A[6 * p + q];
                 if (fabs(apq) < 1e-300) continue;
                 const double tau = (A[6 * q + q] - A[6 * p + p]) / (2 * apq);
                 const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1 + tau * tau));
                 const double c = 1 / sqrt(1 + t * t), s = t * c;
+#pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     const double akp = A[6 * k + p], akq = A[6 * k + q];
                     A[6 * k + p] = c * akp - s * akq;
                     A[6 * k + q] = s * akp + c * akq;
                 }
+#pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     const double apk = A[6 * p + k], aqk = A[6 * q + k];
                     A[6 * p + k] = c * apk - s * aqk;
                     A[6 * q + k] = s * apk + c * aqk;
                 }
+#pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     const double qkp = Q[6 * k + p], qkq = Q[6 * k + q];
                     Q[6 * k + p] = c * qkp - s * qkq;
@@ -168,6 +193,88 @@ __device__ void lo_eigen_sym6(double *A, double *Q)
                 }
             }
     }
+}
+
+// Thread 0: from the 28 block sums to the update x (LO:909-1004 / LM:922-997).  P (6x6, LDS) is
+// the degeneracy projector kept from iteration 0; returns false when fewer than min_rows rows.
+__device__ __noinline__ bool solve_update(const double (&tot)[LSUMS], bool first, double thresh, double *sP,
+                                             int *degenerate, double (&x)[6])
+{
+    double A[36], b[6];
+    {
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) {
+                A[6 * r + c] = tot[k];
+                A[6 * c + r] = tot[k];
+                ++k;
+            }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) b[r] = tot[21 + r];
+    }
+    if (first) {
+        // eigenvalues below the threshold mark degenerate directions: P = V^-1 V2 with rows of V =
+        // eigenvectors = sum over kept eigenvectors q q^T; "kept" = all but the trailing run of
+        // eigenvalues < thresh in descending order
+        double E[36], Q[36];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) E[i] = A[i];
+        lo_eigen_sym6(E, Q);
+        double ev[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ev[i] = E[7 * i];
+        // rank of each eigenvalue in descending order (ties by index), then the kept set
+        int keep = 6;
+        bool kept[6];
+        int rank[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            int r = 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) r += (ev[j] > ev[i] || (ev[j] == ev[i] && j < i)) ? 1 : 0;
+            rank[i] = r;
+        }
+        // walk from the smallest (rank 5) up while below the threshold
+#pragma unroll
+        for (int r = 5; r >= 0; --r) {
+            double e = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) e = rank[i] == r ? ev[i] : e;
+            if (keep == r + 1 && e < thresh) keep = r;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) kept[i] = rank[i] < keep;
+        *degenerate = keep < 6;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double acc = 0;
+                // accumulate in descending-eigenvalue order, as the restatement does
+#pragma unroll
+                for (int k2 = 0; k2 < 6; ++k2)
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+                        if (rank[i] == k2 && kept[i]) acc += Q[6 * r + i] * Q[6 * c + i];
+                sP[6 * r + c] = acc;
+            }
+    }
+    lo_solve_qr6(A, b, x);
+    if (*degenerate) {
+        double x2[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double acc = 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc += sP[6 * r + c] * x[c];
+            x2[r] = acc;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) x[r] = x2[r];
+    }
+    return true;
 }
 
 // Exact 1-NN of p in one indexed cloud (pair b of a GridSet); all lanes of the wave call it.
@@ -180,293 +287,6 @@ __device__ __forceinline__ void lo_nearest(const PairDesc &P, const float4 *__re
     knn_query(P, sorted, cell_start, act, p.x, p.y, p.z, B);
     idx = B.i[0] == 0x7fffffff ? -1 : B.i[0];
     sqd = B.d[0];
-}
-
-__global__ __launch_bounds__(LBLOCK) void loam_odometry_kernel(
-    const SweepDesc *__restrict__ sweeps, const float4 *__restrict__ sharp, const float4 *__restrict__ flat,
-    const float4 *__restrict__ clast, const float4 *__restrict__ slast, const PairDesc *__restrict__ cpairs,
-    const float4 *__restrict__ csorted, const unsigned *__restrict__ ccells, const PairDesc *__restrict__ spairs,
-    const float4 *__restrict__ ssorted, const unsigned *__restrict__ scells, int *__restrict__ corr,
-    const float *__restrict__ tr_in, float *__restrict__ tr_out, int *__restrict__ iters_out,
-    int *__restrict__ nsel_out, const float *__restrict__ sum_in, float *__restrict__ sum_out)
-{
-    __shared__ float tr[6];
-    __shared__ double red[LWAVES][LSUMS];
-    __shared__ double sA[36], sB[6], sX[6], sV[6], sQ[36], sP[36], sE[36];
-    __shared__ int s_flags[3];  // degenerate, done, last nsel
-    const int b = blockIdx.x;
-    const SweepDesc D = sweeps[b];
-    const PairDesc &CP = cpairs[b];
-    const PairDesc &SP = spairs[b];
-    const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off, *cl = clast + D.clast_off,
-                 *sl = slast + D.slast_off;
-    // correspondence indices of this sweep: ci1, ci2 | si1, si2, si3
-    int *ci1 = corr + 2 * D.sharp_off + 3 * D.flat_off, *ci2 = ci1 + D.nc;
-    int *si1 = ci2 + D.nc, *si2 = si1 + D.ns, *si3 = si2 + D.ns;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < 6) tr[threadIdx.x] = tr_in[6 * b + threadIdx.x];
-    if (threadIdx.x < 36) sP[threadIdx.x] = (threadIdx.x % 7 == 0) ? 1.0 : 0.0;
-    if (threadIdx.x == 0) {
-        s_flags[0] = 0;
-        s_flags[1] = 0;
-        s_flags[2] = 0;
-    }
-    for (int i = threadIdx.x; i < D.nc; i += LBLOCK) ci1[i] = ci2[i] = -1;
-    for (int i = threadIdx.x; i < D.ns; i += LBLOCK) si1[i] = si2[i] = si3[i] = -1;
-    __syncthreads();
-    int iters = 0;
-    const bool enough = D.mc > 10 && D.ms > 100;  // LO:569
-    // forward ring scans are bounded by the CURRENT sweep's feature counts (LO:620,776)
-    const int fwd_c = min(D.nc, D.mc), fwd_s = min(D.ns, D.ms);
-
-    for (int it = 0; enough && it < 25; ++it) {  // LO:585
-        ++iters;
-        double sum[LSUMS];
-#pragma unroll
-        for (int k = 0; k < LSUMS; ++k) sum[k] = 0.0;
-        const bool search = it % 5 == 0;
-
-        // ---- corner features: point-to-line (LO:592-746)
-        for (int i0 = 0; i0 < D.nc; i0 += LBLOCK) {
-            const int i = i0 + threadIdx.x;
-            const bool act = i < D.nc;
-            float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act) pi = sh[i];
-            const float4 ps = lo_to_start(tr, pi);
-            if (search) {  // uniform
-                int idx;
-                float sqd;
-                lo_nearest(CP, csorted, ccells, act, ps, idx, sqd);
-                int closest = -1, min2 = -1;
-                if (act && idx >= 0 && sqd < 25) {
-                    closest = idx;
-                    const int scan = (int)cl[closest].w;
-                    float d2min = 25;
-                    for (int j = closest + 1; j < fwd_c; ++j) {
-                        const float4 q = cl[j];
-                        if ((int)q.w > scan + 1.5) break;
-                        const float d = sq3(q, ps);
-                        if ((int)q.w > scan && d < d2min) {
-                            d2min = d;
-                            min2 = j;
-                        }
-                    }
-                    for (int j = closest - 1; j >= 0; --j) {
-                        const float4 q = cl[j];
-                        if ((int)q.w < scan - 1.5) break;
-                        const float d = sq3(q, ps);
-                        if ((int)q.w < scan && d < d2min) {
-                            d2min = d;
-                            min2 = j;
-                        }
-                    }
-                }
-                if (act) {
-                    ci1[i] = closest;
-                    ci2[i] = min2;
-                }
-            }
-            if (act && ci2[i] >= 0) {
-                const float4 t1 = cl[ci1[i]], t2 = cl[ci2[i]];
-                const float x0 = ps.x, y0 = ps.y, z0 = ps.z;
-                const float x1 = t1.x, y1 = t1.y, z1 = t1.z, x2 = t2.x, y2 = t2.y, z2 = t2.z;
-                const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
-                const float m22 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
-                const float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
-                const float a012 = sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
-                const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
-                const float la = ((y1 - y2) * m11 + (z1 - z2) * m22) / a012 / l12;
-                const float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) / a012 / l12;
-                const float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) / a012 / l12;
-                const float ld2 = a012 / l12;
-                float s = 1;
-                if (it >= 5) s = (float)(1 - 1.8 * fabs((double)ld2));
-                if (s > 0.1 && ld2 != 0) lo_row(tr, pi, make_float4(s * la, s * lb, s * lc, s * ld2), sum);
-            }
-        }
-        // ---- surface features: point-to-plane (LO:752-901)
-        for (int i0 = 0; i0 < D.ns; i0 += LBLOCK) {
-            const int i = i0 + threadIdx.x;
-            const bool act = i < D.ns;
-            float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act) pi = fl[i];
-            const float4 ps = lo_to_start(tr, pi);
-            if (search) {
-                int idx;
-                float sqd;
-                lo_nearest(SP, ssorted, scells, act, ps, idx, sqd);
-                int closest = -1, min2 = -1, min3 = -1;
-                if (act && idx >= 0 && sqd < 25) {
-                    closest = idx;
-                    const int scan = (int)sl[closest].w;
-                    float d2 = 25, d3 = 25;
-                    for (int j = closest + 1; j < fwd_s; ++j) {
-                        const float4 q = sl[j];
-                        if ((int)q.w > scan + 1.5) break;
-                        const float d = sq3(q, ps);
-                        if ((int)q.w <= scan) {
-                            if (d < d2) { d2 = d; min2 = j; }
-                        } else {
-                            if (d < d3) { d3 = d; min3 = j; }
-                        }
-                    }
-                    for (int j = closest - 1; j >= 0; --j) {
-                        const float4 q = sl[j];
-                        if ((int)q.w < scan - 1.5) break;
-                        const float d = sq3(q, ps);
-                        if ((int)q.w >= scan) {
-                            if (d < d2) { d2 = d; min2 = j; }
-                        } else {
-                            if (d < d3) { d3 = d; min3 = j; }
-                        }
-                    }
-                }
-                if (act) {
-                    si1[i] = closest;
-                    si2[i] = min2;
-                    si3[i] = min3;
-                }
-            }
-            if (act && si2[i] >= 0 && si3[i] >= 0) {
-                const float4 t1 = sl[si1[i]], t2 = sl[si2[i]], t3 = sl[si3[i]];
-                float pa = (t2.y - t1.y) * (t3.z - t1.z) - (t3.y - t1.y) * (t2.z - t1.z);
-                float pb = (t2.z - t1.z) * (t3.x - t1.x) - (t3.z - t1.z) * (t2.x - t1.x);
-                float pc = (t2.x - t1.x) * (t3.y - t1.y) - (t3.x - t1.x) * (t2.y - t1.y);
-                float pd = -(pa * t1.x + pb * t1.y + pc * t1.z);
-                const float pn = sqrtf(pa * pa + pb * pb + pc * pc);
-                pa /= pn; pb /= pn; pc /= pn; pd /= pn;
-                const float pd2 = pa * ps.x + pb * ps.y + pc * ps.z + pd;
-                float s = 1;
-                if (it >= 5)
-                    s = (float)(1 - 1.8 * fabs((double)pd2) / (double)sqrtf(sqrtf(ps.x * ps.x + ps.y * ps.y + ps.z * ps.z)));
-                if (s > 0.1 && pd2 != 0) lo_row(tr, pi, make_float4(s * pa, s * pb, s * pc, s * pd2), sum);
-            }
-        }
-        // ---- block reduction of the 28 sums (fixed order)
-#pragma unroll
-        for (int k = 0; k < LSUMS; ++k) {
-            const double v = wave_sum(sum[k]);
-            if (lane == 0) red[wave][k] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double tot[LSUMS];
-            for (int k = 0; k < LSUMS; ++k) {
-                double v = 0;
-                for (int w = 0; w < LWAVES; ++w) v += red[w][k];
-                tot[k] = v;
-            }
-            const int nsel = (int)tot[27];
-            s_flags[2] = nsel;
-            if (nsel >= 10) {  // LO:905-907
-                int k = 0;
-                for (int r = 0; r < 6; ++r)
-                    for (int c = r; c < 6; ++c) {
-                        sA[6 * r + c] = tot[k];
-                        sA[6 * c + r] = tot[k];
-                        ++k;
-                    }
-                for (int r = 0; r < 6; ++r) sB[r] = tot[21 + r];
-                if (it == 0) {  // LO:977-997: eigenvalues below 10 mark degenerate directions
-                    for (int i = 0; i < 36; ++i) sE[i] = sA[i];
-                    lo_eigen_sym6(sE, sQ);
-                    // P = V^-1 V2 with rows of V = eigenvectors: P = sum over kept eigenvectors q q^T
-                    // "kept" = all but the trailing run of eigenvalues < 10 in descending order
-                    double ev[6];
-                    int order[6];
-                    for (int i = 0; i < 6; ++i) {
-                        ev[i] = sE[7 * i];
-                        order[i] = i;
-                    }
-                    for (int i = 0; i < 6; ++i)
-                        for (int j = i + 1; j < 6; ++j)
-                            if (ev[order[j]] > ev[order[i]]) {
-                                const int t = order[i];
-                                order[i] = order[j];
-                                order[j] = t;
-                            }
-                    int keep = 6;
-                    while (keep > 0 && ev[order[keep - 1]] < 10.0) --keep;
-                    s_flags[0] = keep < 6;
-                    for (int r = 0; r < 6; ++r)
-                        for (int c = 0; c < 6; ++c) {
-                            double acc = 0;
-                            for (int k2 = 0; k2 < keep; ++k2) acc += sQ[6 * r + order[k2]] * sQ[6 * c + order[k2]];
-                            sP[6 * r + c] = acc;
-                        }
-                }
-                lo_solve_qr6(sA, sB, sX, sV);  // LO:975
-                if (s_flags[0]) {              // LO:999-1003
-                    double x2[6];
-                    for (int r = 0; r < 6; ++r) {
-                        double acc = 0;
-                        for (int c = 0; c < 6; ++c) acc += sP[6 * r + c] * sX[c];
-                        x2[r] = acc;
-                    }
-                    for (int r = 0; r < 6; ++r) sX[r] = x2[r];
-                }
-                float xf[6];
-                for (int k2 = 0; k2 < 6; ++k2) {
-                    xf[k2] = (float)sX[k2];
-                    float v = tr[k2] + xf[k2];
-                    if (isnan(v)) v = 0;  // LO:1012-1015
-                    tr[k2] = v;
-                }
-                const double r2d = 180.0 / 3.14159265358979323846;
-                const float dR = (float)sqrt((xf[0] * r2d) * (xf[0] * r2d) + (xf[1] * r2d) * (xf[1] * r2d) +
-                                             (xf[2] * r2d) * (xf[2] * r2d));
-                const float dT = (float)sqrt(((double)xf[3] * 100) * ((double)xf[3] * 100) +
-                                             ((double)xf[4] * 100) * ((double)xf[4] * 100) +
-                                             ((double)xf[5] * 100) * ((double)xf[5] * 100));
-                if (dR < 0.1 && dT < 0.1) s_flags[1] = 1;  // LO:1026
-            }
-        }
-        __syncthreads();
-        if (s_flags[1]) break;
-    }
-    if (threadIdx.x < 6) tr_out[6 * b + threadIdx.x] = tr[threadIdx.x];
-    if (threadIdx.x == 0) {
-        if (iters_out) iters_out[b] = iters;
-        if (nsel_out) nsel_out[b] = s_flags[2];
-        if (sum_in && sum_out) {
-            // pose accumulation, LO:1035-1064 with zero IMU terms
-            const float *S = sum_in + 6 * b;
-            const float cx = S[0], cy = S[1], cz = S[2];
-            const float lx = -tr[0], ly = (float)(-tr[1] * 1.05), lz = -tr[2];
-            const float srx = cosf(lx) * cosf(cx) * sinf(ly) * sinf(cz) - cosf(cx) * cosf(cz) * sinf(lx) -
-                              cosf(lx) * cosf(ly) * sinf(cx);
-            const float ox = -asinf(srx);
-            const float srycrx = sinf(lx) * (cosf(cy) * sinf(cz) - cosf(cz) * sinf(cx) * sinf(cy)) +
-                                 cosf(lx) * sinf(ly) * (cosf(cy) * cosf(cz) + sinf(cx) * sinf(cy) * sinf(cz)) +
-                                 cosf(lx) * cosf(ly) * cosf(cx) * sinf(cy);
-            const float crycrx = cosf(lx) * cosf(ly) * cosf(cx) * cosf(cy) -
-                                 cosf(lx) * sinf(ly) * (cosf(cz) * sinf(cy) - cosf(cy) * sinf(cx) * sinf(cz)) -
-                                 sinf(lx) * (sinf(cy) * sinf(cz) + cosf(cy) * cosf(cz) * sinf(cx));
-            const float oy = atan2f(srycrx / cosf(ox), crycrx / cosf(ox));
-            const float srzcrx = sinf(cx) * (cosf(lz) * sinf(ly) - cosf(ly) * sinf(lx) * sinf(lz)) +
-                                 cosf(cx) * sinf(cz) * (cosf(ly) * cosf(lz) + sinf(lx) * sinf(ly) * sinf(lz)) +
-                                 cosf(lx) * cosf(cx) * cosf(cz) * sinf(lz);
-            const float crzcrx = cosf(lx) * cosf(lz) * cosf(cx) * cosf(cz) -
-                                 cosf(cx) * sinf(cz) * (cosf(ly) * sinf(lz) - cosf(lz) * sinf(lx) * sinf(ly)) -
-                                 sinf(cx) * (sinf(ly) * sinf(lz) + cosf(ly) * cosf(lz) * sinf(lx));
-            const float oz = atan2f(srzcrx / cosf(ox), crzcrx / cosf(ox));
-            const float rx = ox, ry = oy, rz = oz;
-            const float x1 = cosf(rz) * tr[3] - sinf(rz) * tr[4];
-            const float y1 = sinf(rz) * tr[3] + cosf(rz) * tr[4];
-            const float z1 = (float)(tr[5] * 1.05);
-            const float x2 = x1;
-            const float y2 = cosf(rx) * y1 - sinf(rx) * z1;
-            const float z2 = sinf(rx) * y1 + cosf(rx) * z1;
-            float *O = sum_out + 6 * b;
-            const float acx = -asinf(-sinf(rx));
-            O[0] = acx;
-            O[1] = atan2f(cosf(rx) * sinf(ry) / cosf(acx), cosf(rx) * cosf(ry) / cosf(acx));
-            O[2] = atan2f(cosf(rx) * sinf(rz) / cosf(acx), cosf(rx) * cosf(rz) / cosf(acx));
-            O[3] = S[3] - (cosf(ry) * x2 + sinf(ry) * z2);
-            O[4] = S[4] - y2;
-            O[5] = S[5] - (-sinf(ry) * x2 + cosf(ry) * z2);
-        }
-    }
 }
 
 // ===================================================================================
@@ -620,136 +440,542 @@ __device__ __forceinline__ void lm_row(const LmTrig &g, float4 pt, float4 cf, do
 }
 
 
-__global__ __launch_bounds__(LBLOCK) void loam_mapping_kernel(
+// ---- laserMapping's loop as per-iteration launches.  One sweep has only a few thousand stacked
+// features, so a single workgroup per sweep left the k = 5 searches latency bound on one CU;
+// here every 256-point tile of every sweep is its own workgroup (lm_point_kernel), the 28 sums go
+// through per-tile partials, and a one-wave kernel per sweep reduces them in tile order, solves
+// and updates the transform (lm_solve_kernel).  Launches of sweeps that have converged return at
+// once; the host enqueues all 10 iterations without reading anything back.
+constexpr int PT_BLOCK = 256;
+constexpr int PT_WAVES = PT_BLOCK / 64;
+
+struct IterState {
+    float tr[6];
+    int done, degenerate, iters, nsel;
+    double P[36];
+    int rs_c[18], rs_s[18], mono, pad;  // laserOdometry only: ring tables of the last clouds
+};
+
+__global__ void lm_init_kernel(const MapDesc *__restrict__ sweeps, int nsweeps, const float *__restrict__ tr_in,
+                               IterState *__restrict__ st)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nsweeps) return;
+    IterState &S = st[b];
+    for (int k = 0; k < 6; ++k) S.tr[k] = tr_in[6 * b + k];
+    S.done = !(sweeps[b].mc > 10 && sweeps[b].ms > 100);  // LM:748
+    S.degenerate = 0;
+    S.iters = 0;
+    S.nsel = 0;
+    for (int k = 0; k < 36; ++k) S.P[k] = (k % 7 == 0) ? 1.0 : 0.0;
+}
+
+// block partial of the 28 sums -> partial[(b * tiles_max + tile) * LSUMS + k]
+__device__ __forceinline__ void tile_partial(double (&sum)[LSUMS], double *__restrict__ out)
+{
+    __shared__ double red[PT_WAVES][LSUMS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < LSUMS; ++k) {
+        const double v = wave_sum(sum[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < LSUMS) {
+        double v = 0;
+#pragma unroll
+        for (int w = 0; w < PT_WAVES; ++w) v += red[w][threadIdx.x];
+        out[threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(PT_BLOCK) void lm_point_kernel(
     const MapDesc *__restrict__ sweeps, const float4 *__restrict__ cstack, const float4 *__restrict__ sstack,
     const float4 *__restrict__ cmap, const float4 *__restrict__ smap, const PairDesc *__restrict__ cpairs,
     const float4 *__restrict__ csorted, const unsigned *__restrict__ ccells, const PairDesc *__restrict__ spairs,
-    const float4 *__restrict__ ssorted, const unsigned *__restrict__ scells, const float *__restrict__ tr_in,
-    float *__restrict__ tr_out, int *__restrict__ iters_out, int *__restrict__ nsel_out)
+    const float4 *__restrict__ ssorted, const unsigned *__restrict__ scells, const IterState *__restrict__ st,
+    double *__restrict__ partial, int tiles_max)
 {
-    __shared__ float tr[6];
-    __shared__ double red[LWAVES][LSUMS];
-    __shared__ double sA[36], sB[6], sX[6], sV[6], sQ[36], sP[36], sE[36];
-    __shared__ int s_flags[3];  // degenerate, done, last nsel
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
+    if (st[b].done) return;
     const MapDesc D = sweeps[b];
-    const PairDesc &CP = cpairs[b];
-    const PairDesc &SP = spairs[b];
-    const float4 *cs = cstack + D.cstack_off, *ss = sstack + D.sstack_off, *cm = cmap + D.cmap_off,
-                 *sm = smap + D.smap_off;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < 6) tr[threadIdx.x] = tr_in[6 * b + threadIdx.x];
-    if (threadIdx.x < 36) sP[threadIdx.x] = (threadIdx.x % 7 == 0) ? 1.0 : 0.0;
-    if (threadIdx.x == 0) {
-        s_flags[0] = 0;
-        s_flags[1] = 0;
-        s_flags[2] = 0;
-    }
-    __syncthreads();
-    int iters = 0;
-    const bool enough = D.mc > 10 && D.ms > 100;  // LM:748
-
-    for (int it = 0; enough && it < 10; ++it) {  // LM:752
-        ++iters;
-        double sum[LSUMS];
+    const int ct = (D.nc + PT_BLOCK - 1) / PT_BLOCK, stl = (D.ns + PT_BLOCK - 1) / PT_BLOCK;
+    const int tile = blockIdx.x;
+    if (tile >= ct + stl) return;
+    double sum[LSUMS];
 #pragma unroll
-        for (int k = 0; k < LSUMS; ++k) sum[k] = 0.0;
-        LmTrig g;
+    for (int k = 0; k < LSUMS; ++k) sum[k] = 0.0;
+    LmTrig g;
+    {
+        const float *tr = st[b].tr;
         g.srx = sinf(tr[0]); g.crx = cosf(tr[0]);
         g.sry = sinf(tr[1]); g.cry = cosf(tr[1]);
         g.srz = sinf(tr[2]); g.crz = cosf(tr[2]);
         g.tx = tr[3]; g.ty = tr[4]; g.tz = tr[5];
-
+    }
+    if (tile < ct) {
         // ---- corner features: line through the 5 nearest map corners (LM:756-858)
-        for (int i0 = 0; i0 < D.nc; i0 += LBLOCK) {
-            const int i = i0 + threadIdx.x;
-            const bool act = i < D.nc;
-            float4 po = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act) po = cs[i];
-            const float4 ps = lm_to_map(g, po);
-            Best<5> B;
-            B.init();
-            knn_query(CP, csorted, ccells, act, ps.x, ps.y, ps.z, B);
-            if (act && B.d[4] < 1.0f) {
-                float4 q[5];
+        const float4 *cs = cstack + D.cstack_off, *cm = cmap + D.cmap_off;
+        const int i = tile * PT_BLOCK + threadIdx.x;
+        const bool act = i < D.nc;
+        float4 po = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) po = cs[i];
+        const float4 ps = lm_to_map(g, po);
+        Best<5> B;
+        B.init();
+        knn_query(cpairs[b], csorted, ccells, act, ps.x, ps.y, ps.z, B);
+        if (act && B.d[4] < 1.0f) {
+            float4 q[5];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) q[j] = cm[B.i[j]];
-                float cx = 0, cy = 0, cz = 0;
+            for (int j = 0; j < 5; ++j) q[j] = cm[B.i[j]];
+            float cx = 0, cy = 0, cz = 0;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    cx += q[j].x;
-                    cy += q[j].y;
-                    cz += q[j].z;
+            for (int j = 0; j < 5; ++j) {
+                cx += q[j].x;
+                cy += q[j].y;
+                cz += q[j].z;
+            }
+            cx /= 5; cy /= 5; cz /= 5;
+            float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float ax = q[j].x - cx, ay = q[j].y - cy, az = q[j].z - cz;
+                a11 += ax * ax; a12 += ax * ay; a13 += ax * az;
+                a22 += ay * ay; a23 += ay * az; a33 += az * az;
+            }
+            a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
+            const double A1[9] = {a11, a12, a13, a12, a22, a23, a13, a23, a33};
+            double l1, l2, v1[3];
+            lm_eigen_sym3_top(A1, l1, l2, v1);
+            if ((float)l1 > 3 * (float)l2) {  // LM:812
+                const float x0 = ps.x, y0 = ps.y, z0 = ps.z;
+                const float x1 = (float)((double)cx + 0.1 * (double)(float)v1[0]);
+                const float y1 = (float)((double)cy + 0.1 * (double)(float)v1[1]);
+                const float z1 = (float)((double)cz + 0.1 * (double)(float)v1[2]);
+                const float x2 = (float)((double)cx - 0.1 * (double)(float)v1[0]);
+                const float y2 = (float)((double)cy - 0.1 * (double)(float)v1[1]);
+                const float z2 = (float)((double)cz - 0.1 * (double)(float)v1[2]);
+                const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
+                const float m22 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
+                const float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
+                const float a012 = sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
+                const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+                const float la = ((y1 - y2) * m11 + (z1 - z2) * m22) / a012 / l12;
+                const float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) / a012 / l12;
+                const float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) / a012 / l12;
+                const float ld2 = a012 / l12;
+                const float s = (float)(1 - 0.9 * fabs((double)ld2));
+                if (s > 0.1) lm_row(g, po, make_float4(s * la, s * lb, s * lc, s * ld2), sum);
+            }
+        }
+    } else {
+        // ---- surface features: plane through the 5 nearest map surfels (LM:860-920)
+        const float4 *ss = sstack + D.sstack_off, *sm = smap + D.smap_off;
+        const int i = (tile - ct) * PT_BLOCK + threadIdx.x;
+        const bool act = i < D.ns;
+        float4 po = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) po = ss[i];
+        const float4 ps = lm_to_map(g, po);
+        Best<5> B;
+        B.init();
+        knn_query(spairs[b], ssorted, scells, act, ps.x, ps.y, ps.z, B);
+        if (act && B.d[4] < 1.0f) {
+            float4 q[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) q[j] = sm[B.i[j]];
+            double A0[15], x[3];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                A0[3 * j] = q[j].x;
+                A0[3 * j + 1] = q[j].y;
+                A0[3 * j + 2] = q[j].z;
+            }
+            lm_plane_fit5(A0, x);
+            float pa = (float)x[0], pb = (float)x[1], pc = (float)x[2], pd = 1;
+            const float pn = sqrtf(pa * pa + pb * pb + pc * pc);
+            pa /= pn; pb /= pn; pc /= pn; pd /= pn;
+            bool valid = true;
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                valid = valid && !((double)fabsf(pa * q[j].x + pb * q[j].y + pc * q[j].z + pd) > 0.2);
+            if (valid) {
+                const float pd2 = pa * ps.x + pb * ps.y + pc * ps.z + pd;
+                const float s = (float)(1 - 0.9 * fabs((double)pd2) /
+                                                (double)sqrtf(sqrtf(ps.x * ps.x + ps.y * ps.y + ps.z * ps.z)));
+                if (s > 0.1) lm_row(g, po, make_float4(s * pa, s * pb, s * pc, s * pd2), sum);
+            }
+        }
+    }
+    tile_partial(sum, partial + ((long long)b * tiles_max + tile) * LSUMS);
+}
+
+// one wave per sweep: partials in tile order -> solve -> update (LM:922-1017)
+__global__ __launch_bounds__(64) void lm_solve_kernel(const MapDesc *__restrict__ sweeps, IterState *__restrict__ st,
+                                                      const double *__restrict__ partial, int tiles_max, int it)
+{
+    const int b = blockIdx.x;
+    IterState &S = st[b];
+    if (S.done) return;
+    __shared__ double s_tot[LSUMS];
+    const MapDesc D = sweeps[b];
+    const int tiles = (D.nc + PT_BLOCK - 1) / PT_BLOCK + (D.ns + PT_BLOCK - 1) / PT_BLOCK;
+    if (threadIdx.x < LSUMS) {
+        double v = 0;
+        for (int t = 0; t < tiles; ++t) v += partial[((long long)b * tiles_max + t) * LSUMS + threadIdx.x];
+        s_tot[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double tot[LSUMS];
+#pragma unroll
+    for (int k = 0; k < LSUMS; ++k) tot[k] = s_tot[k];
+    S.iters = it + 1;
+    const int nsel = (int)tot[27];
+    S.nsel = nsel;
+    if (nsel >= 50) {  // LM:929-931; solve LM:968, degeneracy LM:970-997 (threshold 100)
+        double x[6];
+        solve_update(tot, it == 0, 100.0, S.P, &S.degenerate, x);
+        float xf[6];
+#pragma unroll
+        for (int k2 = 0; k2 < 6; ++k2) {
+            xf[k2] = (float)x[k2];
+            S.tr[k2] = S.tr[k2] + xf[k2];
+        }
+        const double r2d = 180.0 / 3.14159265358979323846;
+        const float dR = (float)sqrt((xf[0] * r2d) * (xf[0] * r2d) + (xf[1] * r2d) * (xf[1] * r2d) +
+                                     (xf[2] * r2d) * (xf[2] * r2d));
+        const float dT = (float)sqrt(((double)xf[3] * 100) * ((double)xf[3] * 100) +
+                                     ((double)xf[4] * 100) * ((double)xf[4] * 100) +
+                                     ((double)xf[5] * 100) * ((double)xf[5] * 100));
+        if (dR < 0.05 && dT < 0.05) S.done = 1;  // LM:1015
+    }
+    if (it == 9) S.done = 1;  // LM:752
+}
+
+__global__ void iter_finish_kernel(const IterState *__restrict__ st, int nsweeps, float *__restrict__ tr_out,
+                                   int *__restrict__ iters_out, int *__restrict__ nsel_out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nsweeps) return;
+    for (int k = 0; k < 6; ++k) tr_out[6 * b + k] = st[b].tr[k];
+    if (iters_out) iters_out[b] = st[b].iters;
+    if (nsel_out) nsel_out[b] = st[b].nsel;
+}
+
+// ---- laserOdometry's loop as a few launches per sweep.  The correspondence searches of
+// iterations 0, 5, 10, 15, 20 (three grid searches per feature) are spread over one workgroup per
+// 256 features (lo_search_kernel); the five iterations that share a set of correspondences are
+// cheap and sequential, and run in one workgroup per sweep (lo_iter_kernel).  Converged sweeps
+// return at once, so the host enqueues the whole schedule without reading anything back.
+__global__ __launch_bounds__(PT_BLOCK) void lo_init_kernel(const SweepDesc *__restrict__ sweeps,
+                                                           const float4 *__restrict__ clast,
+                                                           const float4 *__restrict__ slast, int *__restrict__ corr,
+                                                           const float *__restrict__ tr_in, IterState *__restrict__ st)
+{
+    const int b = blockIdx.x;
+    const SweepDesc D = sweeps[b];
+    IterState &S = st[b];
+    __shared__ int s_mono;
+    int *ci1 = corr + 2 * D.sharp_off + 3 * D.flat_off;
+    for (int i = threadIdx.x; i < 2 * D.nc + 3 * D.ns; i += PT_BLOCK) ci1[i] = -1;
+    if (threadIdx.x < 6) S.tr[threadIdx.x] = tr_in[6 * b + threadIdx.x];
+    if (threadIdx.x < 36) S.P[threadIdx.x] = (threadIdx.x % 7 == 0) ? 1.0 : 0.0;
+    if (threadIdx.x < 18) {
+        S.rs_c[threadIdx.x] = D.mc;
+        S.rs_s[threadIdx.x] = D.ms;
+    }
+    if (threadIdx.x == 0) {
+        S.done = !(D.mc > 10 && D.ms > 100);  // LO:569
+        S.degenerate = 0;
+        S.iters = 0;
+        S.nsel = 0;
+        s_mono = 1;
+    }
+    __syncthreads();
+    // ring tables: rs[r] = first point with ring id >= r.  scanRegistration emits the clouds ring by
+    // ring; anything else (ids outside 0..15, ids going down) takes the sequential walks.
+    for (int pass = 0; pass < 2; ++pass) {
+        const float4 *c = pass == 0 ? clast + D.clast_off : slast + D.slast_off;
+        const int m = pass == 0 ? D.mc : D.ms;
+        int *rs = pass == 0 ? S.rs_c : S.rs_s;
+        for (int i = threadIdx.x; i < m; i += PT_BLOCK) {
+            const int ri = (int)c[i].w, rp = i > 0 ? (int)c[i - 1].w : -1;
+            if (ri < rp || ri < 0 || ri > 15) s_mono = 0;
+            else
+                for (int r = rp + 1; r <= ri; ++r) rs[r] = i;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) S.mono = s_mono;
+}
+
+__global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
+    const SweepDesc *__restrict__ sweeps, const float4 *__restrict__ sharp, const float4 *__restrict__ flat,
+    const float4 *__restrict__ clast, const float4 *__restrict__ slast, const PairDesc *__restrict__ cpairs,
+    const float4 *__restrict__ csorted, const unsigned *__restrict__ ccells, const PairDesc *__restrict__ spairs,
+    const float4 *__restrict__ ssorted, const unsigned *__restrict__ scells, int *__restrict__ corr,
+    const IterState *__restrict__ st)
+{
+    const int b = blockIdx.y;
+    if (st[b].done) return;
+    const SweepDesc D = sweeps[b];
+    const int ct = (D.nc + PT_BLOCK - 1) / PT_BLOCK, stl = (D.ns + PT_BLOCK - 1) / PT_BLOCK;
+    const int tile = blockIdx.x;
+    if (tile >= ct + stl) return;
+    __shared__ float tr[6];
+    __shared__ int s_rs_c[18], s_rs_s[18];
+    if (threadIdx.x < 6) tr[threadIdx.x] = st[b].tr[threadIdx.x];
+    if (threadIdx.x < 18) {
+        s_rs_c[threadIdx.x] = st[b].rs_c[threadIdx.x];
+        s_rs_s[threadIdx.x] = st[b].rs_s[threadIdx.x];
+    }
+    __syncthreads();
+    const bool mono = st[b].mono != 0;
+    const PairDesc &CP = cpairs[b];
+    const PairDesc &SP = spairs[b];
+    const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off, *cl = clast + D.clast_off,
+                 *sl = slast + D.slast_off;
+    int *ci1 = corr + 2 * D.sharp_off + 3 * D.flat_off, *ci2 = ci1 + D.nc;
+    int *si1 = ci2 + D.nc, *si2 = si1 + D.ns, *si3 = si2 + D.ns;
+    // forward ring scans are bounded by the CURRENT sweep's feature counts (LO:620,776)
+    const int fwd_c = min(D.nc, D.mc), fwd_s = min(D.ns, D.ms);
+    if (tile < ct) {
+        const int i = tile * PT_BLOCK + threadIdx.x;
+        const bool act = i < D.nc;
+        float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) pi = sh[i];
+        const float4 ps = lo_to_start(tr, pi);
+        int idx;
+        float sqd;
+        lo_nearest(CP, csorted, ccells, act, ps, idx, sqd);
+        int closest = -1, min2 = -1;
+        const bool has = act && idx >= 0 && sqd < 25;
+        if (has) closest = idx;
+        if (mono) {  // wave-uniform: the two walks as one search filtered to the adjacent rings
+            int a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            if (has) {
+                const int scan = (int)cl[closest].w;
+                if (scan >= 1) {
+                    a0 = s_rs_c[scan - 1];
+                    a1 = s_rs_c[scan];
                 }
-                cx /= 5; cy /= 5; cz /= 5;
-                float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
+                b0 = s_rs_c[scan + 1];
+                b1 = min(s_rs_c[scan + 2], fwd_c);
+            }
+            BestRing R;
+            R.init(25.f, closest, a0, a1, b0, b1);
+            knn_query(CP, csorted, ccells, has, ps.x, ps.y, ps.z, R);
+            if (has) min2 = R.i;
+        } else if (has) {
+            const int scan = (int)cl[closest].w;
+            float d2min = 25;
+            // the walks are sequential by definition (first strict minimum wins, stop at the
+            // ring border); RS candidates are fetched per step so the loads overlap
+            for (int j0 = closest + 1, stop = 0; j0 < fwd_c && !stop; j0 += RS) {
+                float4 qq[RS];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    const float ax = q[j].x - cx, ay = q[j].y - cy, az = q[j].z - cz;
-                    a11 += ax * ax; a12 += ax * ay; a13 += ax * az;
-                    a22 += ay * ay; a23 += ay * az; a33 += az * az;
+                for (int u = 0; u < RS; ++u) qq[u] = cl[min(j0 + u, fwd_c - 1)];
+#pragma unroll
+                for (int u = 0; u < RS; ++u) {
+                    const int j = j0 + u;
+                    if (stop || j >= fwd_c) continue;
+                    const float4 q = qq[u];
+                    if ((int)q.w > scan + 1.5) {
+                        stop = 1;
+                        continue;
+                    }
+                    const float d = sq3(q, ps);
+                    if ((int)q.w > scan && d < d2min) {
+                        d2min = d;
+                        min2 = j;
+                    }
                 }
-                a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
-                const double A1[9] = {a11, a12, a13, a12, a22, a23, a13, a23, a33};
-                double l1, l2, v1[3];
-                lm_eigen_sym3_top(A1, l1, l2, v1);
-                if ((float)l1 > 3 * (float)l2) {  // LM:812
-                    const float x0 = ps.x, y0 = ps.y, z0 = ps.z;
-                    const float x1 = (float)((double)cx + 0.1 * (double)(float)v1[0]);
-                    const float y1 = (float)((double)cy + 0.1 * (double)(float)v1[1]);
-                    const float z1 = (float)((double)cz + 0.1 * (double)(float)v1[2]);
-                    const float x2 = (float)((double)cx - 0.1 * (double)(float)v1[0]);
-                    const float y2 = (float)((double)cy - 0.1 * (double)(float)v1[1]);
-                    const float z2 = (float)((double)cz - 0.1 * (double)(float)v1[2]);
-                    const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
-                    const float m22 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
-                    const float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
-                    const float a012 = sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
-                    const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
-                    const float la = ((y1 - y2) * m11 + (z1 - z2) * m22) / a012 / l12;
-                    const float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) / a012 / l12;
-                    const float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) / a012 / l12;
-                    const float ld2 = a012 / l12;
-                    const float s = (float)(1 - 0.9 * fabs((double)ld2));
-                    if (s > 0.1) lm_row(g, po, make_float4(s * la, s * lb, s * lc, s * ld2), sum);
+            }
+            for (int j0 = closest - 1, stop = 0; j0 >= 0 && !stop; j0 -= RS) {
+                float4 qq[RS];
+#pragma unroll
+                for (int u = 0; u < RS; ++u) qq[u] = cl[max(j0 - u, 0)];
+#pragma unroll
+                for (int u = 0; u < RS; ++u) {
+                    const int j = j0 - u;
+                    if (stop || j < 0) continue;
+                    const float4 q = qq[u];
+                    if ((int)q.w < scan - 1.5) {
+                        stop = 1;
+                        continue;
+                    }
+                    const float d = sq3(q, ps);
+                    if ((int)q.w < scan && d < d2min) {
+                        d2min = d;
+                        min2 = j;
+                    }
                 }
             }
         }
-        // ---- surface features: plane through the 5 nearest map surfels (LM:860-920)
+        if (act) {
+            ci1[i] = closest;
+            ci2[i] = min2;
+        }
+    } else {
+        const int i = (tile - ct) * PT_BLOCK + threadIdx.x;
+        const bool act = i < D.ns;
+        float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) pi = fl[i];
+        const float4 ps = lo_to_start(tr, pi);
+        int idx;
+        float sqd;
+        lo_nearest(SP, ssorted, scells, act, ps, idx, sqd);
+        int closest = -1, min2 = -1, min3 = -1;
+        const bool has = act && idx >= 0 && sqd < 25;
+        if (has) closest = idx;
+        if (mono) {  // own ring -> min2, adjacent rings -> min3
+            int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, e0 = 0, e1 = 0;
+            if (has) {
+                const int scan = (int)sl[closest].w;
+                a0 = s_rs_s[scan];
+                a1 = closest;
+                b0 = closest + 1;
+                b1 = min(s_rs_s[scan + 1], fwd_s);
+                if (scan >= 1) {
+                    c0 = s_rs_s[scan - 1];
+                    c1 = s_rs_s[scan];
+                }
+                e0 = s_rs_s[scan + 1];
+                e1 = min(s_rs_s[scan + 2], fwd_s);
+            }
+            BestRing R2, R3;
+            R2.init(25.f, closest, a0, a1, b0, b1);
+            knn_query(SP, ssorted, scells, has, ps.x, ps.y, ps.z, R2);
+            R3.init(25.f, closest, c0, c1, e0, e1);
+            knn_query(SP, ssorted, scells, has, ps.x, ps.y, ps.z, R3);
+            if (has) {
+                min2 = R2.i;
+                min3 = R3.i;
+            }
+        } else if (has) {
+            const int scan = (int)sl[closest].w;
+            float d2 = 25, d3 = 25;
+            for (int j0 = closest + 1, stop = 0; j0 < fwd_s && !stop; j0 += RS) {
+                float4 qq[RS];
+#pragma unroll
+                for (int u = 0; u < RS; ++u) qq[u] = sl[min(j0 + u, fwd_s - 1)];
+#pragma unroll
+                for (int u = 0; u < RS; ++u) {
+                    const int j = j0 + u;
+                    if (stop || j >= fwd_s) continue;
+                    const float4 q = qq[u];
+                    if ((int)q.w > scan + 1.5) {
+                        stop = 1;
+                        continue;
+                    }
+                    const float d = sq3(q, ps);
+                    if ((int)q.w <= scan) {
+                        if (d < d2) { d2 = d; min2 = j; }
+                    } else {
+                        if (d < d3) { d3 = d; min3 = j; }
+                    }
+                }
+            }
+            for (int j0 = closest - 1, stop = 0; j0 >= 0 && !stop; j0 -= RS) {
+                float4 qq[RS];
+#pragma unroll
+                for (int u = 0; u < RS; ++u) qq[u] = sl[max(j0 - u, 0)];
+#pragma unroll
+                for (int u = 0; u < RS; ++u) {
+                    const int j = j0 - u;
+                    if (stop || j < 0) continue;
+                    const float4 q = qq[u];
+                    if ((int)q.w < scan - 1.5) {
+                        stop = 1;
+                        continue;
+                    }
+                    const float d = sq3(q, ps);
+                    if ((int)q.w >= scan) {
+                        if (d < d2) { d2 = d; min2 = j; }
+                    } else {
+                        if (d < d3) { d3 = d; min3 = j; }
+                    }
+                }
+            }
+        }
+        if (act) {
+            si1[i] = closest;
+            si2[i] = min2;
+            si3[i] = min3;
+        }
+    }
+}
+
+// iterations it0 .. it0+4 of one sweep with the correspondences of the preceding search
+__global__ __launch_bounds__(LBLOCK) void lo_iter_kernel(
+    const SweepDesc *__restrict__ sweeps, const float4 *__restrict__ sharp, const float4 *__restrict__ flat,
+    const float4 *__restrict__ clast, const float4 *__restrict__ slast, const int *__restrict__ corr,
+    IterState *__restrict__ st, int it0)
+{
+    const int b = blockIdx.x;
+    IterState &S = st[b];
+    if (S.done) return;
+    __shared__ float tr[6];
+    __shared__ double red[LWAVES][LSUMS];
+    __shared__ int s_done;
+    const SweepDesc D = sweeps[b];
+    const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off, *cl = clast + D.clast_off,
+                 *sl = slast + D.slast_off;
+    const int *ci1 = corr + 2 * D.sharp_off + 3 * D.flat_off, *ci2 = ci1 + D.nc;
+    const int *si1 = ci2 + D.nc, *si2 = si1 + D.ns, *si3 = si2 + D.ns;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 6) tr[threadIdx.x] = S.tr[threadIdx.x];
+    if (threadIdx.x == 0) s_done = 0;
+    __syncthreads();
+    for (int it = it0; it < it0 + 5; ++it) {  // LO:585
+        double sum[LSUMS];
+#pragma unroll
+        for (int k = 0; k < LSUMS; ++k) sum[k] = 0.0;
+        // ---- corner features: point-to-line (LO:680-746)
+        for (int i0 = 0; i0 < D.nc; i0 += LBLOCK) {
+            const int i = i0 + threadIdx.x;
+            const bool act = i < D.nc;
+            float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act) pi = sh[i];
+            const float4 ps = lo_to_start(tr, pi);
+            if (act && ci2[i] >= 0) {
+                const float4 t1 = cl[ci1[i]], t2 = cl[ci2[i]];
+                const float x0 = ps.x, y0 = ps.y, z0 = ps.z;
+                const float x1 = t1.x, y1 = t1.y, z1 = t1.z, x2 = t2.x, y2 = t2.y, z2 = t2.z;
+                const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
+                const float m22 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
+                const float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
+                const float a012 = sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
+                const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+                const float la = ((y1 - y2) * m11 + (z1 - z2) * m22) / a012 / l12;
+                const float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) / a012 / l12;
+                const float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) / a012 / l12;
+                const float ld2 = a012 / l12;
+                float s = 1;
+                if (it >= 5) s = (float)(1 - 1.8 * fabs((double)ld2));
+                if (s > 0.1 && ld2 != 0) lo_row(tr, pi, make_float4(s * la, s * lb, s * lc, s * ld2), sum);
+            }
+        }
+        // ---- surface features: point-to-plane (LO:847-901)
         for (int i0 = 0; i0 < D.ns; i0 += LBLOCK) {
             const int i = i0 + threadIdx.x;
             const bool act = i < D.ns;
-            float4 po = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act) po = ss[i];
-            const float4 ps = lm_to_map(g, po);
-            Best<5> B;
-            B.init();
-            knn_query(SP, ssorted, scells, act, ps.x, ps.y, ps.z, B);
-            if (act && B.d[4] < 1.0f) {
-                float4 q[5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) q[j] = sm[B.i[j]];
-                double A0[15], x[3];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    A0[3 * j] = q[j].x;
-                    A0[3 * j + 1] = q[j].y;
-                    A0[3 * j + 2] = q[j].z;
-                }
-                lm_plane_fit5(A0, x);
-                float pa = (float)x[0], pb = (float)x[1], pc = (float)x[2], pd = 1;
+            float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act) pi = fl[i];
+            const float4 ps = lo_to_start(tr, pi);
+            if (act && si2[i] >= 0 && si3[i] >= 0) {
+                const float4 t1 = sl[si1[i]], t2 = sl[si2[i]], t3 = sl[si3[i]];
+                float pa = (t2.y - t1.y) * (t3.z - t1.z) - (t3.y - t1.y) * (t2.z - t1.z);
+                float pb = (t2.z - t1.z) * (t3.x - t1.x) - (t3.z - t1.z) * (t2.x - t1.x);
+                float pc = (t2.x - t1.x) * (t3.y - t1.y) - (t3.x - t1.x) * (t2.y - t1.y);
+                float pd = -(pa * t1.x + pb * t1.y + pc * t1.z);
                 const float pn = sqrtf(pa * pa + pb * pb + pc * pc);
                 pa /= pn; pb /= pn; pc /= pn; pd /= pn;
-                bool valid = true;
-#pragma unroll
-                for (int j = 0; j < 5; ++j)
-                    valid = valid && !((double)fabsf(pa * q[j].x + pb * q[j].y + pc * q[j].z + pd) > 0.2);
-                if (valid) {
-                    const float pd2 = pa * ps.x + pb * ps.y + pc * ps.z + pd;
-                    const float s = (float)(1 - 0.9 * fabs((double)pd2) /
-                                                    (double)sqrtf(sqrtf(ps.x * ps.x + ps.y * ps.y + ps.z * ps.z)));
-                    if (s > 0.1) lm_row(g, po, make_float4(s * pa, s * pb, s * pc, s * pd2), sum);
-                }
+                const float pd2 = pa * ps.x + pb * ps.y + pc * ps.z + pd;
+                float s = 1;
+                if (it >= 5)
+                    s = (float)(1 - 1.8 * fabs((double)pd2) / (double)sqrtf(sqrtf(ps.x * ps.x + ps.y * ps.y + ps.z * ps.z)));
+                if (s > 0.1 && pd2 != 0) lo_row(tr, pi, make_float4(s * pa, s * pb, s * pc, s * pd2), sum);
             }
         }
         // ---- block reduction of the 28 sums (fixed order)
@@ -761,62 +987,26 @@ __global__ __launch_bounds__(LBLOCK) void loam_mapping_kernel(
         __syncthreads();
         if (threadIdx.x == 0) {
             double tot[LSUMS];
+#pragma unroll
             for (int k = 0; k < LSUMS; ++k) {
                 double v = 0;
+#pragma unroll
                 for (int w = 0; w < LWAVES; ++w) v += red[w][k];
                 tot[k] = v;
             }
+            S.iters = it + 1;
             const int nsel = (int)tot[27];
-            s_flags[2] = nsel;
-            if (nsel >= 50) {  // LM:929-931
-                int k = 0;
-                for (int r = 0; r < 6; ++r)
-                    for (int c = r; c < 6; ++c) {
-                        sA[6 * r + c] = tot[k];
-                        sA[6 * c + r] = tot[k];
-                        ++k;
-                    }
-                for (int r = 0; r < 6; ++r) sB[r] = tot[21 + r];
-                if (it == 0) {  // LM:970-991: eigenvalues below 100 mark degenerate directions
-                    for (int i = 0; i < 36; ++i) sE[i] = sA[i];
-                    lo_eigen_sym6(sE, sQ);
-                    double ev[6];
-                    int order[6];
-                    for (int i = 0; i < 6; ++i) {
-                        ev[i] = sE[7 * i];
-                        order[i] = i;
-                    }
-                    for (int i = 0; i < 6; ++i)
-                        for (int j = i + 1; j < 6; ++j)
-                            if (ev[order[j]] > ev[order[i]]) {
-                                const int t = order[i];
-                                order[i] = order[j];
-                                order[j] = t;
-                            }
-                    int keep = 6;
-                    while (keep > 0 && ev[order[keep - 1]] < 100.0) --keep;
-                    s_flags[0] = keep < 6;
-                    for (int r = 0; r < 6; ++r)
-                        for (int c = 0; c < 6; ++c) {
-                            double acc = 0;
-                            for (int k2 = 0; k2 < keep; ++k2) acc += sQ[6 * r + order[k2]] * sQ[6 * c + order[k2]];
-                            sP[6 * r + c] = acc;
-                        }
-                }
-                lo_solve_qr6(sA, sB, sX, sV);  // LM:968
-                if (s_flags[0]) {              // LM:993-997
-                    double x2[6];
-                    for (int r = 0; r < 6; ++r) {
-                        double acc = 0;
-                        for (int c = 0; c < 6; ++c) acc += sP[6 * r + c] * sX[c];
-                        x2[r] = acc;
-                    }
-                    for (int r = 0; r < 6; ++r) sX[r] = x2[r];
-                }
+            S.nsel = nsel;
+            if (nsel >= 10) {  // LO:905-907; solve LO:975, degeneracy LO:977-1003 (threshold 10)
+                double x[6];
+                solve_update(tot, it == 0, 10.0, S.P, &S.degenerate, x);
                 float xf[6];
+#pragma unroll
                 for (int k2 = 0; k2 < 6; ++k2) {
-                    xf[k2] = (float)sX[k2];
-                    tr[k2] = tr[k2] + xf[k2];
+                    xf[k2] = (float)x[k2];
+                    float v = tr[k2] + xf[k2];
+                    if (isnan(v)) v = 0;  // LO:1012-1015
+                    tr[k2] = v;
                 }
                 const double r2d = 180.0 / 3.14159265358979323846;
                 const float dR = (float)sqrt((xf[0] * r2d) * (xf[0] * r2d) + (xf[1] * r2d) * (xf[1] * r2d) +
@@ -824,16 +1014,68 @@ __global__ __launch_bounds__(LBLOCK) void loam_mapping_kernel(
                 const float dT = (float)sqrt(((double)xf[3] * 100) * ((double)xf[3] * 100) +
                                              ((double)xf[4] * 100) * ((double)xf[4] * 100) +
                                              ((double)xf[5] * 100) * ((double)xf[5] * 100));
-                if (dR < 0.05 && dT < 0.05) s_flags[1] = 1;  // LM:1015
+                if (dR < 0.1 && dT < 0.1) s_done = 1;  // LO:1026
             }
+            if (it == 24) s_done = 1;
         }
         __syncthreads();
-        if (s_flags[1]) break;
+        if (s_done) break;
     }
-    if (threadIdx.x < 6) tr_out[6 * b + threadIdx.x] = tr[threadIdx.x];
-    if (threadIdx.x == 0) {
-        if (iters_out) iters_out[b] = iters;
-        if (nsel_out) nsel_out[b] = s_flags[2];
+    if (threadIdx.x < 6) S.tr[threadIdx.x] = tr[threadIdx.x];
+    if (threadIdx.x == 0 && s_done) S.done = 1;
+}
+
+// results + pose accumulation (LO:1035-1064 with zero IMU terms)
+__global__ void lo_finish_kernel(const IterState *__restrict__ st, int nsweeps, float *__restrict__ tr_out,
+                                 int *__restrict__ iters_out, int *__restrict__ nsel_out,
+                                 const float *__restrict__ sum_in, float *__restrict__ sum_out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nsweeps) return;
+    float tr[6];
+    for (int k = 0; k < 6; ++k) {
+        tr[k] = st[b].tr[k];
+        tr_out[6 * b + k] = tr[k];
+    }
+    if (iters_out) iters_out[b] = st[b].iters;
+    if (nsel_out) nsel_out[b] = st[b].nsel;
+    if (sum_in && sum_out) {
+        // pose accumulation, LO:1035-1064 with zero IMU terms
+        const float *S = sum_in + 6 * b;
+        const float cx = S[0], cy = S[1], cz = S[2];
+        const float lx = -tr[0], ly = (float)(-tr[1] * 1.05), lz = -tr[2];
+        const float srx = cosf(lx) * cosf(cx) * sinf(ly) * sinf(cz) - cosf(cx) * cosf(cz) * sinf(lx) -
+                          cosf(lx) * cosf(ly) * sinf(cx);
+        const float ox = -asinf(srx);
+        const float srycrx = sinf(lx) * (cosf(cy) * sinf(cz) - cosf(cz) * sinf(cx) * sinf(cy)) +
+                             cosf(lx) * sinf(ly) * (cosf(cy) * cosf(cz) + sinf(cx) * sinf(cy) * sinf(cz)) +
+                             cosf(lx) * cosf(ly) * cosf(cx) * sinf(cy);
+        const float crycrx = cosf(lx) * cosf(ly) * cosf(cx) * cosf(cy) -
+                             cosf(lx) * sinf(ly) * (cosf(cz) * sinf(cy) - cosf(cy) * sinf(cx) * sinf(cz)) -
+                             sinf(lx) * (sinf(cy) * sinf(cz) + cosf(cy) * cosf(cz) * sinf(cx));
+        const float oy = atan2f(srycrx / cosf(ox), crycrx / cosf(ox));
+        const float srzcrx = sinf(cx) * (cosf(lz) * sinf(ly) - cosf(ly) * sinf(lx) * sinf(lz)) +
+                             cosf(cx) * sinf(cz) * (cosf(ly) * cosf(lz) + sinf(lx) * sinf(ly) * sinf(lz)) +
+                             cosf(lx) * cosf(cx) * cosf(cz) * sinf(lz);
+        const float crzcrx = cosf(lx) * cosf(lz) * cosf(cx) * cosf(cz) -
+                             cosf(cx) * sinf(cz) * (cosf(ly) * sinf(lz) - cosf(lz) * sinf(lx) * sinf(ly)) -
+                             sinf(cx) * (sinf(ly) * sinf(lz) + cosf(ly) * cosf(lz) * sinf(lx));
+        const float oz = atan2f(srzcrx / cosf(ox), crzcrx / cosf(ox));
+        const float rx = ox, ry = oy, rz = oz;
+        const float x1 = cosf(rz) * tr[3] - sinf(rz) * tr[4];
+        const float y1 = sinf(rz) * tr[3] + cosf(rz) * tr[4];
+        const float z1 = (float)(tr[5] * 1.05);
+        const float x2 = x1;
+        const float y2 = cosf(rx) * y1 - sinf(rx) * z1;
+        const float z2 = sinf(rx) * y1 + cosf(rx) * z1;
+        float *O = sum_out + 6 * b;
+        const float acx = -asinf(-sinf(rx));
+        O[0] = acx;
+        O[1] = atan2f(cosf(rx) * sinf(ry) / cosf(acx), cosf(rx) * cosf(ry) / cosf(acx));
+        O[2] = atan2f(cosf(rx) * sinf(rz) / cosf(acx), cosf(rx) * cosf(rz) / cosf(acx));
+        O[3] = S[3] - (cosf(ry) * x2 + sinf(ry) * z2);
+        O[4] = S[4] - y2;
+        O[5] = S[5] - (-sinf(ry) * x2 + cosf(ry) * z2);
     }
 }
 
@@ -864,19 +1106,30 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
     if (!rc) rc = build_grids(ctx, d_slast, 16, soff, nsweeps, 0.f, MAX_LEVELS, sg);
     if (rc) return rc;
     long long ext_c = 0, ext_f = 0;
+    int tiles_max = 1;
     for (int b = 0; b < nsweeps; ++b) {
         ext_c = std::max(ext_c, descs[b].sharp_off + descs[b].nc);
         ext_f = std::max(ext_f, descs[b].flat_off + descs[b].ns);
+        tiles_max = std::max(tiles_max, div_up(descs[b].nc, PT_BLOCK) + div_up(descs[b].ns, PT_BLOCK));
     }
     DevBuf<SweepDesc> d_sw;
+    DevBuf<IterState> d_st;
     DevBuf<int> corr;
     GPSCAL_HIP(ctx, d_sw.alloc_async(nsweeps, ctx->stream));
+    GPSCAL_HIP(ctx, d_st.alloc_async(nsweeps, ctx->stream));
     GPSCAL_HIP(ctx, corr.alloc_async((size_t)2 * ext_c + (size_t)3 * ext_f + 8, ctx->stream));
     GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, descs, sizeof(SweepDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
-    // the grids index clouds relative to coff[0] / soff[0]
-    hipLaunchKernelGGL(loam_odometry_kernel, dim3(nsweeps), dim3(LBLOCK), 0, ctx->stream, d_sw.p, d_sharp, d_flat,
-                       d_clast, d_slast, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p, sg.cell_start,
-                       corr.p, d_tr_in, d_tr_out, d_iters, d_nsel, d_sum_in, d_sum_out);
+    hipLaunchKernelGGL(lo_init_kernel, dim3(nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_clast, d_slast, corr.p,
+                       d_tr_in, d_st.p);
+    for (int it0 = 0; it0 < 25; it0 += 5) {  // LO:585: a search every fifth iteration (LO:592)
+        hipLaunchKernelGGL(lo_search_kernel, dim3(tiles_max, nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_sharp,
+                           d_flat, d_clast, d_slast, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p,
+                           sg.cell_start, corr.p, d_st.p);
+        hipLaunchKernelGGL(lo_iter_kernel, dim3(nsweeps), dim3(LBLOCK), 0, ctx->stream, d_sw.p, d_sharp, d_flat,
+                           d_clast, d_slast, corr.p, d_st.p, it0);
+    }
+    hipLaunchKernelGGL(lo_finish_kernel, dim3(div_up(nsweeps, 64)), dim3(64), 0, ctx->stream, d_st.p, nsweeps, d_tr_out,
+                       d_iters, d_nsel, d_sum_in, d_sum_out);
     GPSCAL_HIP(ctx, hipGetLastError());
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the grid sets die with this scope
     return GPSCAL_OK;
@@ -954,11 +1207,26 @@ int loam_mapping_device(gpscal_ctx *ctx, int nsweeps, const MapDesc *descs, cons
     if (!rc) rc = build_grids(ctx, d_smap, 16, smoff, nsweeps, 0.f, MAX_LEVELS, sg);
     if (rc) return rc;
     DevBuf<MapDesc> d_sw;
+    DevBuf<IterState> d_st;
+    DevBuf<double> d_part;
+    int tiles_max = 1;
+    for (int b = 0; b < nsweeps; ++b)
+        tiles_max = std::max(tiles_max, div_up(descs[b].nc, PT_BLOCK) + div_up(descs[b].ns, PT_BLOCK));
     GPSCAL_HIP(ctx, d_sw.alloc_async(nsweeps, ctx->stream));
+    GPSCAL_HIP(ctx, d_st.alloc_async(nsweeps, ctx->stream));
+    GPSCAL_HIP(ctx, d_part.alloc_async((size_t)nsweeps * tiles_max * LSUMS, ctx->stream));
     GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, descs, sizeof(MapDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(loam_mapping_kernel, dim3(nsweeps), dim3(LBLOCK), 0, ctx->stream, d_sw.p, d_cstack, d_sstack,
-                       d_cmap, d_smap, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p, sg.cell_start,
-                       d_tr_in, d_tr_out, d_iters, d_nsel);
+    hipLaunchKernelGGL(lm_init_kernel, dim3(div_up(nsweeps, 64)), dim3(64), 0, ctx->stream, d_sw.p, nsweeps, d_tr_in,
+                       d_st.p);
+    for (int it = 0; it < 10; ++it) {  // LM:752; converged sweeps return at once
+        hipLaunchKernelGGL(lm_point_kernel, dim3(tiles_max, nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_cstack,
+                           d_sstack, d_cmap, d_smap, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p,
+                           sg.cell_start, d_st.p, d_part.p, tiles_max);
+        hipLaunchKernelGGL(lm_solve_kernel, dim3(nsweeps), dim3(64), 0, ctx->stream, d_sw.p, d_st.p, d_part.p,
+                           tiles_max, it);
+    }
+    hipLaunchKernelGGL(iter_finish_kernel, dim3(div_up(nsweeps, 64)), dim3(64), 0, ctx->stream, d_st.p, nsweeps,
+                       d_tr_out, d_iters, d_nsel);
     GPSCAL_HIP(ctx, hipGetLastError());
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GPSCAL_OK;
