@@ -110,6 +110,34 @@ def track_path_bench(tmpdir, total_poses=400000, long_len=1200, short_len=400, o
             "note": "the reference additionally replays one cloud per second (input_data.cpp:32,333): its wall time is >= 2 x #clouds s"}
 
 
+def loam_chain_bench(ctx, nseg=6, nsweeps=30, n_az=1800):
+    """The LOAM node chain ahead of the track path: raw 16-ring sweeps of
+    `nseg` synthetic drives -> /true_odometry_to_init samples, all segments in lock step on the GPU;
+    next to it the single-thread CPU restatement on one of the segments."""
+    import _oracle as O
+    from gpscalibration_amd import synth
+    W = synth.lidar_world(0, length=600.0)
+    segs, stamps = [], []
+    for sgm in range(nseg):
+        sw, st, _ = synth.drive(W, nsweeps, seed=100 + sgm, n_az=n_az, start=(20.0 * sgm, 0.3 * sgm))
+        segs.append(sw)
+        stamps.append(st)
+    ctx.loam_run([segs[0][:4]], [stamps[0][:4]])  # warm-up
+    t0 = time.perf_counter()
+    got = ctx.loam_run(segs, stamps)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref = O.loam_run(segs[0], stamps[0])
+    dc = time.perf_counter() - t0
+    dev = float(np.abs(got[0]["track"][1:, :2] - ref["track"][1:, :2]).max())
+    return {"segments": nseg, "sweeps_per_segment": nsweeps, "points_per_sweep": int(len(segs[0][0])),
+            "gpu_seconds": dt, "gpu_sweeps_per_s": nseg * nsweeps / dt,
+            "cpu_port_sweeps_per_s": nsweeps / dc, "cpu_cores": 1,
+            "cpu_sample": "one segment of %d sweeps, %.1f s" % (nsweeps, dc),
+            "track_max_abs_diff_m": dev,
+            "note": "host->device copy of the raw sweeps included; segments advance in lock step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +148,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-track", action="store_true", help="skip the bag->KML (track path) section")
+    ap.add_argument("--no-loam", action="store_true", help="skip the LOAM node chain section")
     ap.add_argument("--no-single-pair", action="store_true",
                     help="skip the single-pair latency probe (keeps rocprof's per-kernel average to the batch launches)")
     args = ap.parse_args()
@@ -239,6 +268,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.iters)
+        if world == 1 and not args.no_loam:
+            out["loam_chain"] = loam_chain_bench(ctx)
         if world == 1 and not args.no_track:
             import tempfile
             with tempfile.TemporaryDirectory() as td:
