@@ -17,7 +17,7 @@ EXPORTS = [
     "gpscal_scan_batch_correspondences", "gpscal_scan_batch_build_seconds", "gpscal_scan_batch_destroy",
     "gpscal_icp_iterate", "gpscal_icp_run",
     "gpscal_loam_odometry_batched", "gpscal_loam_mapping_batched", "gpscal_loam_transform",
-    "gpscal_scan_registration_batched", "gpscal_voxel_grid_batched", "gpscal_loam_run_batched",
+    "gpscal_scan_registration_batched", "gpscal_voxel_grid_batched", "gpscal_loam_run_batched", "gpscal_input_data_run",
     "gpscal_comm_unique_id", "gpscal_comm_init", "gpscal_allgather_chains", "gpscal_comm_destroy",
 ]
 
@@ -96,6 +96,8 @@ def load():
     L.gpscal_scan_registration_batched.argtypes = [vp, i, fp, ip, fp, fp, fp, fp, fp, ip, ip]
     L.gpscal_voxel_grid_batched.argtypes = [vp, i, fp, ip, C.c_float, fp, ip]
     L.gpscal_loam_run_batched.argtypes = [vp, i, fp, ip, ip, dp, fp, fp, fp, dp, ip, i, i]
+    L.gpscal_input_data_run.argtypes = [vp, i, fp, ip, ip, dp, C.c_double, C.c_double, C.c_double, i, ip, ip, ip, ip, ip,
+                                         dp, i, ip, i, i]
     L.gpscal_loam_transform.argtypes = [vp, fp, fp, i, fp, i]
     L.gpscal_comm_unique_id.argtypes = [vp]
     L.gpscal_comm_init.argtypes = [vp, vp, i, i]

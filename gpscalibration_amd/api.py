@@ -285,6 +285,35 @@ class Context:
                         "lm_iters": iters[a:b]})
         return out
 
+    def input_data_run(self, bags, stamps, long_distance, short_distance, overlap_distance, corner_pool_cap=0,
+                       surf_pool_cap=0):
+        """input_data's replay + segmentation around the LOAM chain (input_data.cpp:78-124, 266-444).
+        `bags` = list of lists of raw sweeps; returns a list of dict(flag, bag, first, last, track[n,4])."""
+        nbag = len(bags)
+        flat = [sw for b in bags for sw in b]
+        nsw = len(flat)
+        bag_off = np.zeros(nbag + 1, dtype=np.int32)
+        bag_off[1:] = np.cumsum([len(b) for b in bags])
+        off = np.zeros(nsw + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(a) for a in flat])
+        xyz = np.ascontiguousarray(np.concatenate(flat), dtype=np.float32)
+        st = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64) for x in stamps]))
+        cap_t, cap_r = 2 * nsw + 8, 8 * nsw + 16
+        flag = np.zeros(cap_t, dtype=np.int32)
+        bag = np.zeros(cap_t, dtype=np.int32)
+        first = np.zeros(cap_t, dtype=np.int32)
+        last = np.zeros(cap_t, dtype=np.int32)
+        toff = np.zeros(cap_t + 1, dtype=np.int32)
+        rows = np.zeros((cap_r, 4), dtype=np.float64)
+        nt = np.zeros(1, dtype=np.int32)
+        self._ck(self._L.gpscal_input_data_run(self._h, nbag, _ptr(xyz), _ptr(off), _ptr(bag_off), _ptr(st),
+                                               float(long_distance), float(short_distance), float(overlap_distance),
+                                               cap_t, _ptr(flag), _ptr(bag), _ptr(first), _ptr(last), _ptr(toff),
+                                               _ptr(rows), cap_r, _ptr(nt), int(corner_pool_cap), int(surf_pool_cap)),
+                 "input_data_run")
+        return [{"flag": int(flag[k]), "bag": int(bag[k]), "first": int(first[k]), "last": int(last[k]),
+                 "track": rows[toff[k]:toff[k + 1]].copy()} for k in range(int(nt[0]))]
+
     def loam_transform(self, transform6, pts_xyzi, to_end=False):
         t = np.ascontiguousarray(transform6, dtype=np.float32)
         p = np.ascontiguousarray(pts_xyzi, dtype=np.float32)

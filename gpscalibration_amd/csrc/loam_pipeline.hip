@@ -208,26 +208,39 @@ struct PostDesc {
 
 // LO:1087-1114 (identity != 0: the first sweep seeds the last clouds untransformed, LO:519-538);
 // also stores laserOdometry's transformSum of the sweep.
-__global__ void lo_post_kernel(const PostDesc *__restrict__ descs, const SegState *__restrict__ st,
+__global__ void lo_post_kernel(const PostDesc *__restrict__ descs, SegState *__restrict__ st,
                                const float4 *__restrict__ lsharp, const float4 *__restrict__ lflat,
+                               const float4 *__restrict__ clast_old, const float4 *__restrict__ slast_old,
                                float4 *__restrict__ clast, float4 *__restrict__ slast, float *__restrict__ lo_sum_out)
 {
     const int s = blockIdx.y;
     const PostDesc D = descs[s];
-    if (D.row < 0) return;
+    if (D.row == -1) return;
+    const bool carry = D.row == -2;  // an idle stream keeps its last clouds
     __shared__ float tr[6];
-    if (threadIdx.x < 6) tr[threadIdx.x] = st[s].lo_tr[threadIdx.x];
+    if (threadIdx.x < 6) {
+        if (!carry && D.identity && blockIdx.x == 0) {  // laserOdometry (re)initialises: LO:556-562
+            st[s].lo_tr[threadIdx.x] = 0.f;
+            st[s].lo_sum[threadIdx.x] = 0.f;
+        }
+        tr[threadIdx.x] = (carry || D.identity) ? 0.f : st[s].lo_tr[threadIdx.x];
+    }
     __syncthreads();
     const int n = D.nc + D.ns;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const bool corner = i < D.nc;
         const int j = corner ? i : i - D.nc;
-        float4 p = corner ? lsharp[D.src_c + j] : lflat[D.src_s + j];
-        if (!D.identity) p = dev_to_end(tr, p);
+        float4 p;
+        if (carry) p = corner ? clast_old[D.src_c + j] : slast_old[D.src_s + j];
+        else {
+            p = corner ? lsharp[D.src_c + j] : lflat[D.src_s + j];
+            if (!D.identity) p = dev_to_end(tr, p);
+        }
         if (corner) clast[D.dst_c + j] = p;
         else slast[D.dst_s + j] = p;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 6 && lo_sum_out) lo_sum_out[6 * (long long)D.row + threadIdx.x] = st[s].lo_sum[threadIdx.x];
+    if (!carry && blockIdx.x == 0 && threadIdx.x < 6 && lo_sum_out)
+        lo_sum_out[6 * (long long)D.row + threadIdx.x] = D.identity ? 0.f : st[s].lo_sum[threadIdx.x];
 }
 
 // transformMaintenance: laserOdometryHandler (TM:267-314) + SaveTrailWithTimeTotxt (TM:113-157)
@@ -683,6 +696,349 @@ __global__ void lm_flip_kernel(SegState *__restrict__ st, int nseg)
 
 using namespace gpscal;
 
+namespace {
+
+// The node chain for `nstream` independent streams of sweeps, advanced one sweep per step.  All
+// sweeps are registered (scanRegistration) up front; a step names, per stream, which sweep is
+// published next (or none), and returns what the stream's nodes emitted for it.
+struct LoamPipe {
+    gpscal_ctx *ctx = nullptr;
+    int nstream = 0, nsw = 0;
+    const int *sweep_off = nullptr;
+    std::vector<int> cnt;  // nsw x 5 feature counts
+    int max_ls = 1, max_lf = 1;
+    PipeDims dims{};
+    PipeBufs B{};
+    InArg<float> a_xyz;
+    InArg<double> a_stamps;
+    DevBuf<float4> d_sharp, d_lsharp, d_flat, d_lflat;
+    DevBuf<int> d_counts;
+    DevBuf<SegState> d_state;
+    DevBuf<float4> b_pool[2][2], b_frommap[2], b_stack2[2], b_stack[2], b_newq[2], b_vin[2], b_vout[2];
+    DevBuf<int> b_ts[2][2], b_tc[2][2], b_ns[2], b_nc[2], b_voff[2], b_vcnt[2], b_vocnt[2];
+    DevBuf<unsigned long long> b_keys[2], b_vkeys[2];
+    DevBuf<float4> d_clast[2], d_slast[2], d_cmap, d_smap, d_cstack, d_sstack;
+    DevBuf<PostDesc> d_post;
+    DevBuf<PrepDesc> d_prep;
+    DevBuf<PackDesc> d_pack;
+    DevBuf<int> d_rows, d_sizes, d_status, d_iters, d_nsel, d_step_it;
+    DevBuf<float> d_tr, d_tr2, d_step_lo, d_step_lm, d_step_tm;
+    DevBuf<double> d_step_track, d_step_stamp;
+    std::vector<PostDesc> hpost;
+    std::vector<PrepDesc> hprep;
+    std::vector<PackDesc> hpack;
+    std::vector<SweepDesc> hsw;
+    std::vector<MapDesc> hmap;
+    std::vector<int> hrows, hsizes;
+    std::vector<long long> coff, soff, coff_new, soff_new, cmoff, smoff;
+    std::vector<double> hstamp;
+    // per-stream host state of laserOdometry's bookkeeping
+    std::vector<int> local_t;      // sweeps since the last (re)initialisation; 0 = the next sweep seeds
+    std::vector<int> frame_count;  // LO:495,1099-1127
+    int lastbuf = 0;
+    const double *h_stamps = nullptr;
+
+    int init(gpscal_ctx *c, int nstream_, const float *xyz, const int *sweep_off_, int nsw_, const double *stamps,
+             int corner_cap, int surf_cap)
+    {
+        ctx = c;
+        nstream = nstream_;
+        nsw = nsw_;
+        sweep_off = sweep_off_;
+        h_stamps = stamps;
+        hipStream_t q = ctx->stream;
+        const size_t npts = (size_t)std::max(sweep_off[nsw], 1);
+        GPSCAL_HIP(ctx, a_xyz.bind(ctx, xyz, npts * 3));
+        DevBuf<float4> d_full;
+        GPSCAL_HIP(ctx, d_full.alloc(npts));
+        GPSCAL_HIP(ctx, d_sharp.alloc((size_t)nsw * 1536));
+        GPSCAL_HIP(ctx, d_lsharp.alloc((size_t)nsw * 1920));
+        GPSCAL_HIP(ctx, d_flat.alloc((size_t)nsw * 3072));
+        GPSCAL_HIP(ctx, d_lflat.alloc(npts));
+        GPSCAL_HIP(ctx, d_counts.alloc((size_t)nsw * 5));
+        int sr_status = 0;
+        int rc = scan_registration_device(ctx, nsw, sweep_off, sweep_off, a_xyz.dev, d_full.p, d_sharp.p, d_lsharp.p,
+                                          d_flat.p, d_lflat.p, d_counts.p, &sr_status);
+        if (rc) return rc;
+        if (sr_status & 2) return fail(ctx, GPSCAL_ESIZE, "LOAM chain: a sweep has more than 60000 ring points");
+        if (sr_status & 1) return fail(ctx, GPSCAL_ERANGE, "LOAM chain: less-flat capacity exceeded (sweep with missing rings)");
+        cnt.resize((size_t)nsw * 5);
+        GPSCAL_HIP(ctx, hipMemcpyAsync(cnt.data(), d_counts.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, q));
+        GPSCAL_HIP(ctx, hipStreamSynchronize(q));
+        for (int g = 0; g < nsw; ++g) {
+            max_ls = std::max(max_ls, cnt[5 * g + 2]);
+            max_lf = std::max(max_lf, cnt[5 * g + 4]);
+        }
+        dims.nseg = nstream;
+        dims.cap[0] = corner_cap > 0 ? corner_cap : 1 << 18;
+        dims.cap[1] = surf_cap > 0 ? surf_cap : 1 << 20;
+        dims.stack_cap[0] = max_ls;
+        dims.stack_cap[1] = max_lf;
+        for (int t = 0; t < 2; ++t) {
+            int np2 = 1;
+            while (np2 < dims.stack_cap[t]) np2 <<= 1;
+            dims.key_cap[t] = np2;
+        }
+        const int nseg = nstream;
+        GPSCAL_HIP(ctx, d_state.alloc(nseg));
+        GPSCAL_HIP(ctx, hipMemsetAsync(d_state.p, 0, sizeof(SegState) * nseg, q));
+        for (int t = 0; t < 2; ++t) {
+            const size_t vcap = (size_t)dims.cap[t] + dims.stack_cap[t];
+            for (int k = 0; k < 2; ++k) {
+                GPSCAL_HIP(ctx, b_pool[t][k].alloc((size_t)nseg * dims.cap[t]));
+                GPSCAL_HIP(ctx, b_ts[t][k].alloc((size_t)nseg * LNUM));
+                GPSCAL_HIP(ctx, b_tc[t][k].alloc((size_t)nseg * LNUM));
+                GPSCAL_HIP(ctx, hipMemsetAsync(b_ts[t][k].p, 0, sizeof(int) * (size_t)nseg * LNUM, q));
+                GPSCAL_HIP(ctx, hipMemsetAsync(b_tc[t][k].p, 0, sizeof(int) * (size_t)nseg * LNUM, q));
+                B.pool[t][k] = b_pool[t][k].p;
+                B.tab_start[t][k] = b_ts[t][k].p;
+                B.tab_cnt[t][k] = b_tc[t][k].p;
+            }
+            GPSCAL_HIP(ctx, b_frommap[t].alloc((size_t)nseg * dims.cap[t]));
+            GPSCAL_HIP(ctx, b_stack2[t].alloc((size_t)nseg * dims.stack_cap[t]));
+            GPSCAL_HIP(ctx, b_stack[t].alloc((size_t)nseg * dims.stack_cap[t]));
+            GPSCAL_HIP(ctx, b_newq[t].alloc((size_t)nseg * dims.stack_cap[t]));
+            GPSCAL_HIP(ctx, b_ns[t].alloc((size_t)nseg * LNUM));
+            GPSCAL_HIP(ctx, b_nc[t].alloc((size_t)nseg * LNUM));
+            GPSCAL_HIP(ctx, b_vin[t].alloc((size_t)nseg * vcap));
+            GPSCAL_HIP(ctx, b_vout[t].alloc((size_t)nseg * vcap));
+            GPSCAL_HIP(ctx, b_voff[t].alloc((size_t)nseg * MAXVALID));
+            GPSCAL_HIP(ctx, b_vcnt[t].alloc((size_t)nseg * MAXVALID));
+            GPSCAL_HIP(ctx, b_vocnt[t].alloc((size_t)nseg * MAXVALID));
+            GPSCAL_HIP(ctx, b_keys[t].alloc((size_t)nseg * dims.key_cap[t]));
+            GPSCAL_HIP(ctx, b_vkeys[t].alloc((size_t)nseg * 2 * vcap));
+            B.frommap[t] = b_frommap[t].p;
+            B.stack2[t] = b_stack2[t].p;
+            B.stack[t] = b_stack[t].p;
+            B.newq[t] = b_newq[t].p;
+            B.new_start[t] = b_ns[t].p;
+            B.new_cnt[t] = b_nc[t].p;
+            B.vin[t] = b_vin[t].p;
+            B.vout[t] = b_vout[t].p;
+            B.vin_off[t] = b_voff[t].p;
+            B.vin_cnt[t] = b_vcnt[t].p;
+            B.vout_cnt[t] = b_vocnt[t].p;
+            B.keys[t] = b_keys[t].p;
+            B.vkeys[t] = b_vkeys[t].p;
+        }
+        for (int k = 0; k < 2; ++k) {
+            GPSCAL_HIP(ctx, d_clast[k].alloc((size_t)nseg * max_ls));
+            GPSCAL_HIP(ctx, d_slast[k].alloc((size_t)nseg * max_lf));
+        }
+        GPSCAL_HIP(ctx, d_cmap.alloc((size_t)nseg * dims.cap[0]));
+        GPSCAL_HIP(ctx, d_smap.alloc((size_t)nseg * dims.cap[1]));
+        GPSCAL_HIP(ctx, d_cstack.alloc((size_t)nseg * dims.stack_cap[0]));
+        GPSCAL_HIP(ctx, d_sstack.alloc((size_t)nseg * dims.stack_cap[1]));
+        GPSCAL_HIP(ctx, d_post.alloc(nseg));
+        GPSCAL_HIP(ctx, d_prep.alloc(nseg));
+        GPSCAL_HIP(ctx, d_pack.alloc(nseg));
+        GPSCAL_HIP(ctx, d_rows.alloc(nseg));
+        GPSCAL_HIP(ctx, d_sizes.alloc((size_t)nseg * 4));
+        GPSCAL_HIP(ctx, d_status.alloc(1));
+        GPSCAL_HIP(ctx, d_iters.alloc(nseg));
+        GPSCAL_HIP(ctx, d_nsel.alloc(nseg));
+        GPSCAL_HIP(ctx, d_tr.alloc((size_t)nseg * 6));
+        GPSCAL_HIP(ctx, d_tr2.alloc((size_t)nseg * 6));
+        GPSCAL_HIP(ctx, d_step_lo.alloc((size_t)nseg * 6));
+        GPSCAL_HIP(ctx, d_step_lm.alloc((size_t)nseg * 6));
+        GPSCAL_HIP(ctx, d_step_tm.alloc((size_t)nseg * 6));
+        GPSCAL_HIP(ctx, d_step_track.alloc((size_t)nseg * 4));
+        GPSCAL_HIP(ctx, d_step_stamp.alloc((size_t)nseg));
+        GPSCAL_HIP(ctx, d_step_it.alloc((size_t)nseg));
+        GPSCAL_HIP(ctx, hipMemsetAsync(d_status.p, 0, sizeof(int), q));
+        hpost.resize(nseg);
+        hprep.resize(nseg);
+        hpack.resize(nseg);
+        hsw.resize(nseg);
+        hmap.resize(nseg);
+        hrows.resize(nseg);
+        hsizes.resize((size_t)nseg * 4);
+        hstamp.resize(nseg);
+        coff.assign(nseg + 1, 0);
+        soff.assign(nseg + 1, 0);
+        coff_new.assign(nseg + 1, 0);
+        soff_new.assign(nseg + 1, 0);
+        cmoff.assign(nseg + 1, 0);
+        smoff.assign(nseg + 1, 0);
+        local_t.assign(nseg, 0);
+        frame_count.assign(nseg, 1);  // skipFrameNum, LO:495
+        return GPSCAL_OK;
+    }
+
+    // /control_command with systemInited = false (ID:283-286, 342-346; LO:411-415)
+    void control_reset(int s) { local_t[s] = 0; }
+
+    // One sweep per stream (sweep_idx[s] < 0: the stream idles).  Host outputs, nstream rows each:
+    // published[s] (odometry emitted), mapped[s] (laserMapping ran), lo / lm / tm poses, track, iters.
+    int step(const int *sweep_idx, int *published, int *mapped, float *lo, float *lm, float *tm, double *track,
+             int *iters)
+    {
+        hipStream_t q = ctx->stream;
+        const int nseg = nstream;
+        SegState *S = d_state.p;
+        const int newbuf = lastbuf ^ 1;
+        const size_t lds_keys = sizeof(unsigned long long) * LDS_KEYS;
+        coff_new[0] = soff_new[0] = 0;
+        bool any_match = false, any_tm = false, any_map = false;
+        std::vector<int> do_map(nseg, 0);
+        for (int s = 0; s < nseg; ++s) {
+            const int g = sweep_idx[s];
+            const bool act = g >= 0;
+            const bool seed = act && local_t[s] == 0;
+            hrows[s] = act && !seed ? s : -1;  // odometry (and everything after it) is published
+            hstamp[s] = act ? h_stamps[g] : 0.0;
+            PostDesc &P = hpost[s];
+            P.row = act ? s : -1;
+            P.nc = act ? cnt[5 * g + 2] : 0;
+            P.ns = act ? cnt[5 * g + 4] : 0;
+            P.src_c = act ? (long long)g * 1920 : 0;
+            P.src_s = act ? sweep_off[g] : 0;
+            P.dst_c = coff_new[s];
+            P.dst_s = soff_new[s];
+            P.identity = seed;
+            // an idle stream keeps its last clouds: carry them over untouched
+            if (!act) {
+                P.nc = (int)(coff[s + 1] - coff[s]);
+                P.ns = (int)(soff[s + 1] - soff[s]);
+                P.row = -2;  // copy only
+                P.src_c = coff[s];
+                P.src_s = soff[s];
+            }
+            coff_new[s + 1] = coff_new[s] + P.nc;
+            soff_new[s + 1] = soff_new[s] + P.ns;
+            SweepDesc &D = hsw[s];
+            D.sharp_off = act ? (long long)g * 1536 : 0;
+            D.flat_off = act ? (long long)g * 3072 : 0;
+            D.clast_off = coff[s];
+            D.slast_off = soff[s];
+            D.nc = act && !seed ? cnt[5 * g + 1] : 0;
+            D.ns = act && !seed ? cnt[5 * g + 3] : 0;
+            // LO:520-521,571: after a (re)initialisation the counters are still 0 for one sweep
+            const bool matchable = act && local_t[s] >= 2;
+            D.mc = matchable ? (int)(coff[s + 1] - coff[s]) : 0;
+            D.ms = matchable ? (int)(soff[s + 1] - soff[s]) : 0;
+            any_match = any_match || (act && !seed);
+            published[s] = act && !seed;
+            any_tm = any_tm || published[s];
+            if (published[s]) {
+                if (++frame_count[s] >= 2) {  // skipFrameNum + 1, LO:1099-1127
+                    frame_count[s] = 0;
+                    do_map[s] = 1;
+                    any_map = true;
+                }
+            }
+            mapped[s] = do_map[s];
+        }
+        GPSCAL_HIP(ctx, hipMemcpyAsync(d_rows.p, hrows.data(), sizeof(int) * nseg, hipMemcpyHostToDevice, q));
+        GPSCAL_HIP(ctx, hipMemcpyAsync(d_post.p, hpost.data(), sizeof(PostDesc) * nseg, hipMemcpyHostToDevice, q));
+        GPSCAL_HIP(ctx, hipMemcpyAsync(d_step_stamp.p, hstamp.data(), sizeof(double) * nseg, hipMemcpyHostToDevice, q));
+        GPSCAL_HIP(ctx, hipMemsetAsync(d_step_lm.p, 0xff, sizeof(float) * 6 * nseg, q));
+        GPSCAL_HIP(ctx, hipMemsetAsync(d_step_tm.p, 0xff, sizeof(float) * 6 * nseg, q));
+        GPSCAL_HIP(ctx, hipMemsetAsync(d_step_track.p, 0xff, sizeof(double) * 4 * nseg, q));
+        GPSCAL_HIP(ctx, hipMemsetAsync(d_step_it.p, 0xff, sizeof(int) * nseg, q));
+        if (any_match) {
+            // transform / transformSum live in SegState; the kernels take flat [nstream][6] arrays.  A
+            // stream that idles or seeds has empty clouds here: its state passes through unchanged
+            // (zero transform accumulates to itself only for a zero sum, so those rows are restored).
+            GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr.p, 24, &S[0].lo_tr[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
+            GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr2.p, 24, &S[0].lo_sum[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
+            int rc = loam_odometry_device(ctx, nseg, hsw.data(), d_sharp.p, d_flat.p, d_clast[lastbuf].p, d_slast[lastbuf].p,
+                                          coff.data(), soff.data(), d_tr.p, d_tr.p, nullptr, nullptr, d_tr2.p, d_tr2.p);
+            if (rc) return rc;
+            for (int s = 0; s < nseg; ++s)
+                if (published[s]) {
+                    GPSCAL_HIP(ctx, hipMemcpyAsync(&S[s].lo_tr[0], d_tr.p + 6 * s, 24, hipMemcpyDeviceToDevice, q));
+                    GPSCAL_HIP(ctx, hipMemcpyAsync(&S[s].lo_sum[0], d_tr2.p + 6 * s, 24, hipMemcpyDeviceToDevice, q));
+                }
+        }
+        {
+            const int gx = std::max(1, std::min(div_up(std::max(max_ls + max_lf, 1), 256), 64));
+            hipLaunchKernelGGL(lo_post_kernel, dim3(gx, nseg), dim3(256), 0, q, d_post.p, S, d_lsharp.p, d_lflat.p,
+                               d_clast[lastbuf].p, d_slast[lastbuf].p, d_clast[newbuf].p, d_slast[newbuf].p,
+                               d_step_lo.p);
+            GPSCAL_HIP(ctx, hipGetLastError());
+        }
+        lastbuf = newbuf;
+        coff = coff_new;
+        soff = soff_new;
+        if (any_tm) {
+            hipLaunchKernelGGL(tm_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, d_rows.p, d_step_stamp.p, nseg,
+                               d_step_tm.p, d_step_track.p);
+            GPSCAL_HIP(ctx, hipGetLastError());
+        }
+        if (any_map) {
+            for (int s = 0; s < nseg; ++s) {
+                PrepDesc &P = hprep[s];
+                P.clast_off = coff[s];
+                P.slast_off = soff[s];
+                P.nc = (int)(coff[s + 1] - coff[s]);
+                P.ns = (int)(soff[s + 1] - soff[s]);
+                P.active = do_map[s];
+                P.pad = 0;
+                hrows[s] = do_map[s] ? s : -1;
+            }
+            GPSCAL_HIP(ctx, hipMemcpyAsync(d_rows.p, hrows.data(), sizeof(int) * nseg, hipMemcpyHostToDevice, q));
+            GPSCAL_HIP(ctx, hipMemcpyAsync(d_prep.p, hprep.data(), sizeof(PrepDesc) * nseg, hipMemcpyHostToDevice, q));
+            hipLaunchKernelGGL(lm_prepare_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, d_prep.p, S, dims, B,
+                               d_clast[lastbuf].p, d_slast[lastbuf].p, d_sizes.p, d_status.p);
+            GPSCAL_HIP(ctx, hipGetLastError());
+            GPSCAL_HIP(ctx, hipMemcpyAsync(hsizes.data(), d_sizes.p, sizeof(int) * hsizes.size(), hipMemcpyDeviceToHost, q));
+            GPSCAL_HIP(ctx, hipStreamSynchronize(q));
+            cmoff[0] = smoff[0] = 0;
+            long long cso = 0, sso = 0;
+            int nmax = 1;
+            for (int s = 0; s < nseg; ++s) {
+                const int mc = hsizes[4 * s], ms = hsizes[4 * s + 1], nc = hsizes[4 * s + 2], ns = hsizes[4 * s + 3];
+                PackDesc &P = hpack[s];
+                P.dst[0] = cmoff[s]; P.dst[1] = smoff[s]; P.dst[2] = cso; P.dst[3] = sso;
+                P.n[0] = mc; P.n[1] = ms; P.n[2] = nc; P.n[3] = ns;
+                MapDesc &M = hmap[s];
+                M.cmap_off = cmoff[s]; M.smap_off = smoff[s]; M.cstack_off = cso; M.sstack_off = sso;
+                M.mc = mc; M.ms = ms; M.nc = nc; M.ns = ns;
+                cmoff[s + 1] = cmoff[s] + mc;
+                smoff[s + 1] = smoff[s] + ms;
+                cso += nc;
+                sso += ns;
+                nmax = std::max(nmax, std::max(std::max(mc, ms), std::max(nc, ns)));
+            }
+            GPSCAL_HIP(ctx, hipMemcpyAsync(d_pack.p, hpack.data(), sizeof(PackDesc) * nseg, hipMemcpyHostToDevice, q));
+            hipLaunchKernelGGL(lm_pack_kernel, dim3(std::max(1, std::min(div_up(nmax, 256), 128)), nseg), dim3(256), 0, q,
+                               d_pack.p, dims, B, d_cmap.p, d_smap.p, d_cstack.p, d_sstack.p);
+            GPSCAL_HIP(ctx, hipGetLastError());
+            GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr.p, 24, &S[0].tTobe[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
+            int rc = loam_mapping_device(ctx, nseg, hmap.data(), d_cstack.p, d_sstack.p, d_cmap.p, d_smap.p, cmoff.data(),
+                                         smoff.data(), d_tr.p, d_tr2.p, d_iters.p, d_nsel.p);
+            if (rc) return rc;
+            hipLaunchKernelGGL(lm_insert_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, S, dims, B, d_sizes.p, d_tr2.p,
+                               d_iters.p, d_rows.p, d_step_lm.p, d_step_it.p, d_status.p);
+            hipLaunchKernelGGL(lm_filter_kernel, dim3(MAXVALID, nseg * 2), dim3(SBLOCK), lds_keys, q, S, dims, B, d_status.p);
+            hipLaunchKernelGGL(lm_rebuild_kernel, dim3(nseg * 2), dim3(SBLOCK), 0, q, S, dims, B, d_status.p);
+            hipLaunchKernelGGL(lm_flip_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, nseg);
+            GPSCAL_HIP(ctx, hipGetLastError());
+        }
+        if (lo) GPSCAL_HIP(ctx, hipMemcpyAsync(lo, d_step_lo.p, sizeof(float) * 6 * nseg, hipMemcpyDeviceToHost, q));
+        if (lm) GPSCAL_HIP(ctx, hipMemcpyAsync(lm, d_step_lm.p, sizeof(float) * 6 * nseg, hipMemcpyDeviceToHost, q));
+        if (tm) GPSCAL_HIP(ctx, hipMemcpyAsync(tm, d_step_tm.p, sizeof(float) * 6 * nseg, hipMemcpyDeviceToHost, q));
+        if (iters) GPSCAL_HIP(ctx, hipMemcpyAsync(iters, d_step_it.p, sizeof(int) * nseg, hipMemcpyDeviceToHost, q));
+        GPSCAL_HIP(ctx, hipMemcpyAsync(track, d_step_track.p, sizeof(double) * 4 * nseg, hipMemcpyDeviceToHost, q));
+        GPSCAL_HIP(ctx, hipStreamSynchronize(q));
+        for (int s = 0; s < nseg; ++s)
+            if (sweep_idx[s] >= 0) ++local_t[s];
+        return GPSCAL_OK;
+    }
+
+    int finish()
+    {
+        int st = 0;
+        GPSCAL_HIP(ctx, hipMemcpy(&st, d_status.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (st & 8) return fail(ctx, GPSCAL_ENOMEM, "LOAM chain: map pool capacity exceeded (raise corner_pool_cap / surf_pool_cap)");
+        if (st & 4) return fail(ctx, GPSCAL_ERANGE, "LOAM chain: internal scratch capacity exceeded");
+        return GPSCAL_OK;
+    }
+};
+
+}  // namespace
+
 extern "C" int gpscal_loam_run_batched(gpscal_ctx *ctx, int nseg, const float *xyz, const int *sweep_off,
                                        const int *seg_sweep_off, const double *stamps, float *lo_sum_out,
                                        float *lm_aft_out, float *tm_mapped_out, double *track_xyzt, int *lm_iters_out,
@@ -690,6 +1046,9 @@ extern "C" int gpscal_loam_run_batched(gpscal_ctx *ctx, int nseg, const float *x
 {
     if (!ctx || nseg < 1 || !xyz || !sweep_off || !seg_sweep_off || !stamps || !track_xyzt)
         return fail(ctx, GPSCAL_EINVAL, "gpscal_loam_run_batched: bad argument");
+    if (is_device_ptr(stamps) || is_device_ptr(track_xyzt) || is_device_ptr(lo_sum_out) || is_device_ptr(lm_aft_out) ||
+        is_device_ptr(tm_mapped_out) || is_device_ptr(lm_iters_out))
+        return fail(ctx, GPSCAL_EINVAL, "gpscal_loam_run_batched: stamps and the per-sweep outputs are host arrays");
     GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
     const int nsw = seg_sweep_off[nseg] - seg_sweep_off[0];
     if (nsw < 1 || seg_sweep_off[0] != 0) return fail(ctx, GPSCAL_EINVAL, "gpscal_loam_run_batched: bad segment offsets");
@@ -698,269 +1057,189 @@ extern "C" int gpscal_loam_run_batched(gpscal_ctx *ctx, int nseg, const float *x
         if (seg_sweep_off[s + 1] < seg_sweep_off[s]) return fail(ctx, GPSCAL_EINVAL, "gpscal_loam_run_batched: bad segment offsets");
         tmax = std::max(tmax, seg_sweep_off[s + 1] - seg_sweep_off[s]);
     }
-    const size_t npts = (size_t)std::max(sweep_off[nsw], 1);
-    hipStream_t q = ctx->stream;
-
-    // ---- scanRegistration of every sweep
-    InArg<float> a_xyz;
-    InArg<double> a_stamps;
-    GPSCAL_HIP(ctx, a_xyz.bind(ctx, xyz, npts * 3));
-    GPSCAL_HIP(ctx, a_stamps.bind(ctx, stamps, (size_t)nsw));
-    DevBuf<float4> d_full, d_sharp, d_lsharp, d_flat, d_lflat;
-    DevBuf<int> d_counts;
-    GPSCAL_HIP(ctx, d_full.alloc(npts));
-    GPSCAL_HIP(ctx, d_sharp.alloc((size_t)nsw * 1536));
-    GPSCAL_HIP(ctx, d_lsharp.alloc((size_t)nsw * 1920));
-    GPSCAL_HIP(ctx, d_flat.alloc((size_t)nsw * 3072));
-    GPSCAL_HIP(ctx, d_lflat.alloc(npts));
-    GPSCAL_HIP(ctx, d_counts.alloc((size_t)nsw * 5));
-    int sr_status = 0;
-    int rc = scan_registration_device(ctx, nsw, sweep_off, sweep_off, a_xyz.dev, d_full.p, d_sharp.p, d_lsharp.p,
-                                      d_flat.p, d_lflat.p, d_counts.p, &sr_status);
+    LoamPipe P;
+    int rc = P.init(ctx, nseg, xyz, sweep_off, nsw, stamps, corner_pool_cap, surf_pool_cap);
     if (rc) return rc;
-    if (sr_status & 2) return fail(ctx, GPSCAL_ESIZE, "gpscal_loam_run_batched: a sweep has more than 60000 ring points");
-    if (sr_status & 1) return fail(ctx, GPSCAL_ERANGE, "gpscal_loam_run_batched: less-flat capacity exceeded (sweep with missing rings)");
-    std::vector<int> cnt((size_t)nsw * 5);
-    GPSCAL_HIP(ctx, hipMemcpyAsync(cnt.data(), d_counts.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, q));
-    GPSCAL_HIP(ctx, hipStreamSynchronize(q));
-    d_full.release();
-    int max_ls = 1, max_lf = 1;
-    for (int g = 0; g < nsw; ++g) {
-        max_ls = std::max(max_ls, cnt[5 * g + 2]);
-        max_lf = std::max(max_lf, cnt[5 * g + 4]);
-    }
-
-    // ---- state and map buffers
-    PipeDims dims;
-    dims.nseg = nseg;
-    dims.cap[0] = corner_pool_cap > 0 ? corner_pool_cap : 1 << 18;
-    dims.cap[1] = surf_pool_cap > 0 ? surf_pool_cap : 1 << 20;
-    dims.stack_cap[0] = max_ls;
-    dims.stack_cap[1] = max_lf;
-    for (int t = 0; t < 2; ++t) {
-        int np2 = 1;
-        while (np2 < dims.stack_cap[t]) np2 <<= 1;
-        dims.key_cap[t] = np2;
-    }
-    DevBuf<SegState> d_state;
-    GPSCAL_HIP(ctx, d_state.alloc(nseg));
-    GPSCAL_HIP(ctx, hipMemsetAsync(d_state.p, 0, sizeof(SegState) * nseg, q));
-    PipeBufs B;
-    DevBuf<float4> b_pool[2][2], b_frommap[2], b_stack2[2], b_stack[2], b_newq[2], b_vin[2], b_vout[2];
-    DevBuf<int> b_ts[2][2], b_tc[2][2], b_ns[2], b_nc[2], b_voff[2], b_vcnt[2], b_vocnt[2];
-    DevBuf<unsigned long long> b_keys[2], b_vkeys[2];
-    for (int t = 0; t < 2; ++t) {
-        const size_t vcap = (size_t)dims.cap[t] + dims.stack_cap[t];
-        for (int k = 0; k < 2; ++k) {
-            GPSCAL_HIP(ctx, b_pool[t][k].alloc((size_t)nseg * dims.cap[t]));
-            GPSCAL_HIP(ctx, b_ts[t][k].alloc((size_t)nseg * LNUM));
-            GPSCAL_HIP(ctx, b_tc[t][k].alloc((size_t)nseg * LNUM));
-            GPSCAL_HIP(ctx, hipMemsetAsync(b_ts[t][k].p, 0, sizeof(int) * (size_t)nseg * LNUM, q));
-            GPSCAL_HIP(ctx, hipMemsetAsync(b_tc[t][k].p, 0, sizeof(int) * (size_t)nseg * LNUM, q));
-            B.pool[t][k] = b_pool[t][k].p;
-            B.tab_start[t][k] = b_ts[t][k].p;
-            B.tab_cnt[t][k] = b_tc[t][k].p;
-        }
-        GPSCAL_HIP(ctx, b_frommap[t].alloc((size_t)nseg * dims.cap[t]));
-        GPSCAL_HIP(ctx, b_stack2[t].alloc((size_t)nseg * dims.stack_cap[t]));
-        GPSCAL_HIP(ctx, b_stack[t].alloc((size_t)nseg * dims.stack_cap[t]));
-        GPSCAL_HIP(ctx, b_newq[t].alloc((size_t)nseg * dims.stack_cap[t]));
-        GPSCAL_HIP(ctx, b_ns[t].alloc((size_t)nseg * LNUM));
-        GPSCAL_HIP(ctx, b_nc[t].alloc((size_t)nseg * LNUM));
-        GPSCAL_HIP(ctx, b_vin[t].alloc((size_t)nseg * vcap));
-        GPSCAL_HIP(ctx, b_vout[t].alloc((size_t)nseg * vcap));
-        GPSCAL_HIP(ctx, b_voff[t].alloc((size_t)nseg * MAXVALID));
-        GPSCAL_HIP(ctx, b_vcnt[t].alloc((size_t)nseg * MAXVALID));
-        GPSCAL_HIP(ctx, b_vocnt[t].alloc((size_t)nseg * MAXVALID));
-        GPSCAL_HIP(ctx, b_keys[t].alloc((size_t)nseg * dims.key_cap[t]));
-        GPSCAL_HIP(ctx, b_vkeys[t].alloc((size_t)nseg * 2 * vcap));
-        B.frommap[t] = b_frommap[t].p;
-        B.stack2[t] = b_stack2[t].p;
-        B.stack[t] = b_stack[t].p;
-        B.newq[t] = b_newq[t].p;
-        B.new_start[t] = b_ns[t].p;
-        B.new_cnt[t] = b_nc[t].p;
-        B.vin[t] = b_vin[t].p;
-        B.vout[t] = b_vout[t].p;
-        B.vin_off[t] = b_voff[t].p;
-        B.vin_cnt[t] = b_vcnt[t].p;
-        B.vout_cnt[t] = b_vocnt[t].p;
-        B.keys[t] = b_keys[t].p;
-        B.vkeys[t] = b_vkeys[t].p;
-    }
-    // last clouds (double buffered), packed map / stack clouds, per-step scalars
-    DevBuf<float4> d_clast[2], d_slast[2], d_cmap, d_smap, d_cstack, d_sstack;
-    for (int k = 0; k < 2; ++k) {
-        GPSCAL_HIP(ctx, d_clast[k].alloc((size_t)nseg * max_ls));
-        GPSCAL_HIP(ctx, d_slast[k].alloc((size_t)nseg * max_lf));
-    }
-    GPSCAL_HIP(ctx, d_cmap.alloc((size_t)nseg * dims.cap[0]));
-    GPSCAL_HIP(ctx, d_smap.alloc((size_t)nseg * dims.cap[1]));
-    GPSCAL_HIP(ctx, d_cstack.alloc((size_t)nseg * dims.stack_cap[0]));
-    GPSCAL_HIP(ctx, d_sstack.alloc((size_t)nseg * dims.stack_cap[1]));
-    DevBuf<PostDesc> d_post;
-    DevBuf<PrepDesc> d_prep;
-    DevBuf<PackDesc> d_pack;
-    DevBuf<int> d_rows, d_sizes, d_status, d_iters, d_nsel;
-    DevBuf<float> d_tr, d_tr2;
-    GPSCAL_HIP(ctx, d_post.alloc(nseg));
-    GPSCAL_HIP(ctx, d_prep.alloc(nseg));
-    GPSCAL_HIP(ctx, d_pack.alloc(nseg));
-    GPSCAL_HIP(ctx, d_rows.alloc(nseg));
-    GPSCAL_HIP(ctx, d_sizes.alloc((size_t)nseg * 4));
-    GPSCAL_HIP(ctx, d_status.alloc(1));
-    GPSCAL_HIP(ctx, d_iters.alloc(nseg));
-    GPSCAL_HIP(ctx, d_nsel.alloc(nseg));
-    GPSCAL_HIP(ctx, d_tr.alloc((size_t)nseg * 6));
-    GPSCAL_HIP(ctx, d_tr2.alloc((size_t)nseg * 6));
-    GPSCAL_HIP(ctx, hipMemsetAsync(d_status.p, 0, sizeof(int), q));
-    OutArg<float> o_lo, o_lm, o_tm;
-    OutArg<double> o_track;
-    OutArg<int> o_it;
-    GPSCAL_HIP(ctx, o_lo.bind(ctx, lo_sum_out, lo_sum_out ? (size_t)nsw * 6 : 0));
-    GPSCAL_HIP(ctx, o_lm.bind(ctx, lm_aft_out, lm_aft_out ? (size_t)nsw * 6 : 0));
-    GPSCAL_HIP(ctx, o_tm.bind(ctx, tm_mapped_out, tm_mapped_out ? (size_t)nsw * 6 : 0));
-    GPSCAL_HIP(ctx, o_track.bind(ctx, track_xyzt, (size_t)nsw * 4));
-    GPSCAL_HIP(ctx, o_it.bind(ctx, lm_iters_out, lm_iters_out ? (size_t)nsw : 0));
-    // rows no node writes stay NaN / -1 (sweep 0 of a segment; sweeps without a mapping cycle)
-    if (o_lm.dev) GPSCAL_HIP(ctx, hipMemsetAsync(o_lm.dev, 0xff, sizeof(float) * (size_t)nsw * 6, q));
-    if (o_tm.dev) GPSCAL_HIP(ctx, hipMemsetAsync(o_tm.dev, 0xff, sizeof(float) * (size_t)nsw * 6, q));
-    if (o_it.dev) GPSCAL_HIP(ctx, hipMemsetAsync(o_it.dev, 0xff, sizeof(int) * (size_t)nsw, q));
-    GPSCAL_HIP(ctx, hipMemsetAsync(o_track.dev, 0xff, sizeof(double) * (size_t)nsw * 4, q));
-
-    const size_t lds_keys = sizeof(unsigned long long) * LDS_KEYS;
-    std::vector<PostDesc> hpost(nseg);
-    std::vector<PrepDesc> hprep(nseg);
-    std::vector<PackDesc> hpack(nseg);
-    std::vector<SweepDesc> hsw(nseg);
-    std::vector<MapDesc> hmap(nseg);
-    std::vector<int> hrows(nseg), hsizes((size_t)nseg * 4);
-    std::vector<long long> coff(nseg + 1), soff(nseg + 1), coff_new(nseg + 1), soff_new(nseg + 1), cmoff(nseg + 1),
-        smoff(nseg + 1);
-    int lastbuf = 0;
-    for (int s = 0; s <= nseg; ++s) coff[s] = soff[s] = 0;
-    SegState *S = d_state.p;
-    // the odometry kernel reads / writes transform and transformSum through flat arrays
-    auto state_f = [&](size_t member_off) { return reinterpret_cast<float *>(reinterpret_cast<char *>(S) + member_off); };
-    (void)state_f;
-
+    std::vector<int> idx(nseg), pub(nseg), mapd(nseg), its(nseg);
+    std::vector<float> lo((size_t)nseg * 6), lm((size_t)nseg * 6), tm((size_t)nseg * 6);
+    std::vector<double> tr((size_t)nseg * 4);
+    const float fnan = std::nanf("");
+    const double dnan = std::nan("");
     for (int t = 0; t < tmax; ++t) {
-        const int newbuf = lastbuf ^ 1;
-        // ---- laserOdometry (LO:565-1085); nothing to match against at t = 0, and at t = 1 the
-        // reference's stale counters (LO:520-521) skip the loop as well
-        coff_new[0] = soff_new[0] = 0;
-        for (int s = 0; s < nseg; ++s) {
-            const int ns_s = seg_sweep_off[s + 1] - seg_sweep_off[s];
-            const bool act = t < ns_s;
-            const int g = seg_sweep_off[s] + t;
-            hrows[s] = act ? g : -1;
-            PostDesc &P = hpost[s];
-            P.row = act ? g : -1;
-            P.nc = act ? cnt[5 * g + 2] : 0;
-            P.ns = act ? cnt[5 * g + 4] : 0;
-            P.src_c = (long long)g * 1920;
-            P.src_s = act ? sweep_off[g] : 0;
-            P.dst_c = coff_new[s];
-            P.dst_s = soff_new[s];
-            P.identity = t == 0;
-            coff_new[s + 1] = coff_new[s] + P.nc;
-            soff_new[s + 1] = soff_new[s] + P.ns;
-            SweepDesc &D = hsw[s];
-            D.sharp_off = (long long)g * 1536;
-            D.flat_off = (long long)g * 3072;
-            D.clast_off = coff[s];
-            D.slast_off = soff[s];
-            D.nc = act ? cnt[5 * g + 1] : 0;
-            D.ns = act ? cnt[5 * g + 3] : 0;
-            const bool matchable = act && t >= 2;
-            D.mc = matchable ? (int)(coff[s + 1] - coff[s]) : 0;
-            D.ms = matchable ? (int)(soff[s + 1] - soff[s]) : 0;
-        }
-        GPSCAL_HIP(ctx, hipMemcpyAsync(d_rows.p, hrows.data(), sizeof(int) * nseg, hipMemcpyHostToDevice, q));
-        GPSCAL_HIP(ctx, hipMemcpyAsync(d_post.p, hpost.data(), sizeof(PostDesc) * nseg, hipMemcpyHostToDevice, q));
-        if (t >= 1) {
-            // transform / transformSum live in SegState; the kernel takes flat [nseg][6] arrays
-            GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr.p, 24, &S[0].lo_tr[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
-            GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr2.p, 24, &S[0].lo_sum[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
-            rc = loam_odometry_device(ctx, nseg, hsw.data(), d_sharp.p, d_flat.p, d_clast[lastbuf].p, d_slast[lastbuf].p,
-                                      coff.data(), soff.data(), d_tr.p, d_tr.p, nullptr, nullptr, d_tr2.p, d_tr2.p);
-            if (rc) return rc;
-            GPSCAL_HIP(ctx, hipMemcpy2DAsync(&S[0].lo_tr[0], sizeof(SegState), d_tr.p, 24, 24, nseg, hipMemcpyDeviceToDevice, q));
-            GPSCAL_HIP(ctx, hipMemcpy2DAsync(&S[0].lo_sum[0], sizeof(SegState), d_tr2.p, 24, 24, nseg, hipMemcpyDeviceToDevice, q));
-        }
-        {
-            const int gx = std::max(1, std::min(div_up(std::max(max_ls + max_lf, 1), 256), 64));
-            hipLaunchKernelGGL(lo_post_kernel, dim3(gx, nseg), dim3(256), 0, q, d_post.p, S, d_lsharp.p, d_lflat.p,
-                               d_clast[newbuf].p, d_slast[newbuf].p, o_lo.dev);
-            GPSCAL_HIP(ctx, hipGetLastError());
-        }
-        lastbuf = newbuf;
-        coff = coff_new;
-        soff = soff_new;
-        if (t == 0) continue;
-        // ---- transformMaintenance on the odometry of this sweep
-        hipLaunchKernelGGL(tm_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, d_rows.p, a_stamps.dev, nseg, o_tm.dev,
-                           o_track.dev);
-        GPSCAL_HIP(ctx, hipGetLastError());
-        if ((t & 1) == 0) continue;  // skipFrameNum = 1: laserMapping sees every second sweep (LO:1099-1127)
-        // ---- laserMapping
-        for (int s = 0; s < nseg; ++s) {
-            PrepDesc &P = hprep[s];
-            P.clast_off = coff[s];
-            P.slast_off = soff[s];
-            P.nc = (int)(coff[s + 1] - coff[s]);
-            P.ns = (int)(soff[s + 1] - soff[s]);
-            P.active = hrows[s] >= 0;
-            P.pad = 0;
-        }
-        GPSCAL_HIP(ctx, hipMemcpyAsync(d_prep.p, hprep.data(), sizeof(PrepDesc) * nseg, hipMemcpyHostToDevice, q));
-        hipLaunchKernelGGL(lm_prepare_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, d_prep.p, S, dims, B,
-                           d_clast[lastbuf].p, d_slast[lastbuf].p, d_sizes.p, d_status.p);
-        GPSCAL_HIP(ctx, hipGetLastError());
-        GPSCAL_HIP(ctx, hipMemcpyAsync(hsizes.data(), d_sizes.p, sizeof(int) * hsizes.size(), hipMemcpyDeviceToHost, q));
-        GPSCAL_HIP(ctx, hipStreamSynchronize(q));
-        cmoff[0] = smoff[0] = 0;
-        long long cso = 0, sso = 0;
-        int nmax = 1;
-        for (int s = 0; s < nseg; ++s) {
-            const int mc = hsizes[4 * s], ms = hsizes[4 * s + 1], nc = hsizes[4 * s + 2], ns = hsizes[4 * s + 3];
-            PackDesc &P = hpack[s];
-            P.dst[0] = cmoff[s]; P.dst[1] = smoff[s]; P.dst[2] = cso; P.dst[3] = sso;
-            P.n[0] = mc; P.n[1] = ms; P.n[2] = nc; P.n[3] = ns;
-            MapDesc &M = hmap[s];
-            M.cmap_off = cmoff[s]; M.smap_off = smoff[s]; M.cstack_off = cso; M.sstack_off = sso;
-            M.mc = mc; M.ms = ms; M.nc = nc; M.ns = ns;
-            cmoff[s + 1] = cmoff[s] + mc;
-            smoff[s + 1] = smoff[s] + ms;
-            cso += nc;
-            sso += ns;
-            nmax = std::max(nmax, std::max(std::max(mc, ms), std::max(nc, ns)));
-        }
-        GPSCAL_HIP(ctx, hipMemcpyAsync(d_pack.p, hpack.data(), sizeof(PackDesc) * nseg, hipMemcpyHostToDevice, q));
-        hipLaunchKernelGGL(lm_pack_kernel, dim3(std::max(1, std::min(div_up(nmax, 256), 128)), nseg), dim3(256), 0, q,
-                           d_pack.p, dims, B, d_cmap.p, d_smap.p, d_cstack.p, d_sstack.p);
-        GPSCAL_HIP(ctx, hipGetLastError());
-        GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr.p, 24, &S[0].tTobe[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
-        rc = loam_mapping_device(ctx, nseg, hmap.data(), d_cstack.p, d_sstack.p, d_cmap.p, d_smap.p, cmoff.data(),
-                                 smoff.data(), d_tr.p, d_tr2.p, d_iters.p, d_nsel.p);
+        for (int s = 0; s < nseg; ++s) idx[s] = t < seg_sweep_off[s + 1] - seg_sweep_off[s] ? seg_sweep_off[s] + t : -1;
+        rc = P.step(idx.data(), pub.data(), mapd.data(), lo.data(), lm.data(), tm.data(), tr.data(), its.data());
         if (rc) return rc;
-        hipLaunchKernelGGL(lm_insert_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, S, dims, B, d_sizes.p, d_tr2.p,
-                           d_iters.p, d_rows.p, o_lm.dev, o_it.dev, d_status.p);
-        hipLaunchKernelGGL(lm_filter_kernel, dim3(MAXVALID, nseg * 2), dim3(SBLOCK), lds_keys, q, S, dims, B, d_status.p);
-        hipLaunchKernelGGL(lm_rebuild_kernel, dim3(nseg * 2), dim3(SBLOCK), 0, q, S, dims, B, d_status.p);
-        hipLaunchKernelGGL(lm_flip_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, nseg);
-        GPSCAL_HIP(ctx, hipGetLastError());
+        for (int s = 0; s < nseg; ++s) {
+            const int g = idx[s];
+            if (g < 0) continue;
+            for (int k = 0; k < 6; ++k) {
+                if (lo_sum_out) lo_sum_out[6 * (size_t)g + k] = lo[6 * s + k];
+                if (lm_aft_out) lm_aft_out[6 * (size_t)g + k] = mapd[s] ? lm[6 * s + k] : fnan;
+                if (tm_mapped_out) tm_mapped_out[6 * (size_t)g + k] = pub[s] ? tm[6 * s + k] : fnan;
+            }
+            for (int k = 0; k < 4; ++k) track_xyzt[4 * (size_t)g + k] = pub[s] ? tr[4 * s + k] : dnan;
+            if (lm_iters_out) lm_iters_out[g] = mapd[s] ? its[s] : -1;
+        }
     }
-    int st = 0;
-    GPSCAL_HIP(ctx, hipMemcpyAsync(&st, d_status.p, sizeof(int), hipMemcpyDeviceToHost, q));
-    bool sync = true;
-    GPSCAL_HIP(ctx, o_lo.commit(ctx, &sync));
-    GPSCAL_HIP(ctx, o_lm.commit(ctx, &sync));
-    GPSCAL_HIP(ctx, o_tm.commit(ctx, &sync));
-    GPSCAL_HIP(ctx, o_track.commit(ctx, &sync));
-    GPSCAL_HIP(ctx, o_it.commit(ctx, &sync));
-    GPSCAL_HIP(ctx, hipStreamSynchronize(q));
-    if (st & 8) return fail(ctx, GPSCAL_ENOMEM, "gpscal_loam_run_batched: map pool capacity exceeded (raise corner_pool_cap / surf_pool_cap)");
-    if (st & 4) return fail(ctx, GPSCAL_ERANGE, "gpscal_loam_run_batched: internal scratch capacity exceeded");
+    return P.finish();
+}
+
+// input_data's replay + segmentation (input_data.cpp:78-124, 266-444) for nbag independent bags and
+// both passes: stream 2*b is bag b's long pass, stream 2*b+1 its short pass; all streams advance in
+// lock step, each with its own cursor, rewinds and laserOdometry resets.
+extern "C" int gpscal_input_data_run(gpscal_ctx *ctx, int nbag, const float *xyz, const int *sweep_off,
+                                     const int *bag_sweep_off, const double *stamps, double long_distance,
+                                     double short_distance, double overlap_distance, int cap_tracks, int *track_flag,
+                                     int *track_bag, int *seg_first, int *seg_last, int *track_off,
+                                     double *track_xyzt, int cap_rows, int *ntracks_out, int corner_pool_cap,
+                                     int surf_pool_cap)
+{
+    if (!ctx || nbag < 1 || !xyz || !sweep_off || !bag_sweep_off || !stamps || !track_flag || !track_bag || !seg_first ||
+        !seg_last || !track_off || !track_xyzt || !ntracks_out || cap_tracks < 1 || cap_rows < 1)
+        return fail(ctx, GPSCAL_EINVAL, "gpscal_input_data_run: bad argument");
+    if (!(long_distance > short_distance && short_distance > overlap_distance && overlap_distance > 0))  // ID:235-247
+        return fail(ctx, GPSCAL_EINVAL, "gpscal_input_data_run: need long > short > overlap > 0");
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    const int nsw = bag_sweep_off[nbag];
+    if (bag_sweep_off[0] != 0 || nsw < 1) return fail(ctx, GPSCAL_EINVAL, "gpscal_input_data_run: bad bag offsets");
+    const int nstream = 2 * nbag;
+    LoamPipe P;
+    int rc = P.init(ctx, nstream, xyz, sweep_off, nsw, stamps, corner_pool_cap, surf_pool_cap);
+    if (rc) return rc;
+    struct Loc {
+        int idx;
+        double distance, timestamp;
+    };
+    struct Track {
+        int first, last;
+        std::vector<double> rows;
+    };
+    struct Stream {
+        int bag = 0, n = 0, base = 0;  // sweeps of the bag: base .. base + n (message index i <-> sweep base + i - 1)
+        double L = 0, ov = 0;
+        std::vector<Loc> all;
+        Loc pub{0, 0, 0};
+        double total = 0;
+        bool have_pre = false;
+        double pre[3] = {0, 0, 0};
+        int next = 1;        // next message index to publish
+        int phase = 0;       // 0 = segments, 1 = rest replay, 2 = done
+        bool crossed = false;
+        Track cur;
+        std::vector<Track> tracks;
+        int seg_first = 1;
+    };
+    std::vector<Stream> st(nstream);
+    for (int b = 0; b < nbag; ++b)
+        for (int pass = 0; pass < 2; ++pass) {
+            Stream &S = st[2 * b + pass];
+            S.bag = b;
+            S.base = bag_sweep_off[b];
+            S.n = bag_sweep_off[b + 1] - bag_sweep_off[b];
+            S.L = pass == 0 ? long_distance : short_distance;
+            S.ov = pass == 0 ? 0.0 : overlap_distance;
+            S.all.push_back(S.pub);  // ID:269-273
+            S.next = 1;
+            S.cur.first = 1;
+            S.cur.last = 0;
+            if (S.n < 1) S.phase = 2;
+        }
+    std::vector<int> idx(nstream), pub(nstream), mapd(nstream);
+    std::vector<double> tr((size_t)nstream * 4);
+    // ends the track being collected (ID:347-352) and decides what the stream does next
+    auto close_track = [&](Stream &S, int s, bool end_by_distance) {
+        S.tracks.push_back(S.cur);
+        S.have_pre = false;
+        if (S.phase == 1) {  // the rest replay is over
+            S.phase = 2;
+            return;
+        }
+        if (end_by_distance && S.pub.idx < S.n) {  // next segment: everything after pubLocation, fresh LOAM
+            P.control_reset(s);
+            S.next = S.pub.idx + 1;
+            S.cur = Track{S.next, S.next - 1, {}};
+            return;
+        }
+        // the bag is exhausted; is the rest too short?  (ID:366-414)
+        if (S.all.size() > 1 && S.total < S.L / 3.0) {
+            const Loc tmp = S.all[S.all.size() - 2];
+            const int drop = S.tracks.size() >= 2 ? 2 : (int)S.tracks.size();
+            S.tracks.resize(S.tracks.size() - drop);
+            P.control_reset(s);
+            S.phase = 1;
+            S.next = tmp.idx + 1;
+            S.cur = Track{S.next, S.next - 1, {}};
+            if (S.next > S.n) S.phase = 2;
+            return;
+        }
+        S.phase = 2;
+    };
+    for (;;) {
+        bool any = false;
+        for (int s = 0; s < nstream; ++s) {
+            Stream &S = st[s];
+            idx[s] = -1;
+            if (S.phase == 2) continue;
+            if (S.next > S.n) {  // ran off the end of the bag (ID:341: the inner loop ends without `end`)
+                if (S.phase == 1 && S.cur.rows.empty()) S.phase = 2;  // ID:419: an empty track is not queued
+                else close_track(S, s, false);
+                if (S.phase == 2 || S.next > S.n) {
+                    if (S.phase != 2 && S.next > S.n) S.phase = 2;
+                    continue;
+                }
+            }
+            idx[s] = S.base + S.next - 1;
+            any = true;
+        }
+        if (!any) break;
+        rc = P.step(idx.data(), pub.data(), mapd.data(), nullptr, nullptr, nullptr, tr.data(), nullptr);
+        if (rc) return rc;
+        for (int s = 0; s < nstream; ++s) {
+            Stream &S = st[s];
+            if (idx[s] < 0) continue;
+            const int i = S.next;
+            S.cur.last = i;
+            ++S.next;
+            if (pub[s]) {  // subOdometryHandler, ID:78-118
+                const double *t4 = tr.data() + 4 * s;
+                S.cur.rows.insert(S.cur.rows.end(), t4, t4 + 4);
+                Loc t;
+                t.idx = i;
+                t.distance = S.have_pre ? std::sqrt((t4[0] - S.pre[0]) * (t4[0] - S.pre[0]) + (t4[1] - S.pre[1]) * (t4[1] - S.pre[1]) +
+                                                    (t4[2] - S.pre[2]) * (t4[2] - S.pre[2])) + S.total
+                                        : 0.0;
+                t.timestamp = t4[3];
+                S.have_pre = true;
+                S.pre[0] = t4[0]; S.pre[1] = t4[1]; S.pre[2] = t4[2];
+                if (S.phase == 0) {
+                    if (t.distance <= S.L - S.ov) S.pub = t;
+                    else if (S.all.back().timestamp != S.pub.timestamp) S.all.push_back(S.pub);
+                }
+                S.total = t.distance;
+            }
+            if (S.phase == 0 && S.total > S.L) {  // ID:332-339
+                S.total = 0;
+                close_track(S, s, true);
+            }
+        }
+    }
+    rc = P.finish();
+    if (rc) return rc;
+    int nt = 0, nrows = 0;
+    track_off[0] = 0;
+    for (int pass = 0; pass < 2; ++pass)  // input_data publishes every long track before the first short one
+        for (int b = 0; b < nbag; ++b)
+            for (const Track &T : st[2 * b + pass].tracks) {
+                if (nt >= cap_tracks || nrows + (int)T.rows.size() / 4 > cap_rows)
+                    return fail(ctx, GPSCAL_ESIZE, "gpscal_input_data_run: output capacity exceeded");
+                track_flag[nt] = pass;
+                track_bag[nt] = b;
+                seg_first[nt] = T.first;
+                seg_last[nt] = T.last;
+                std::memcpy(track_xyzt + 4 * (size_t)nrows, T.rows.data(), sizeof(double) * T.rows.size());
+                nrows += (int)T.rows.size() / 4;
+                track_off[++nt] = nrows;
+            }
+    *ntracks_out = nt;
     return GPSCAL_OK;
 }

@@ -305,6 +305,26 @@ int gpscal_loam_run_batched(gpscal_ctx *ctx, int nseg, const float *xyz,
                             float *tm_mapped, double *track_xyzt, int *lm_iters,
                             int corner_pool_cap, int surf_pool_cap);
 
+/* Replaces input_data_node's replay + segmentation (input_data.cpp:78-124, 266-444) together with
+ * the LOAM nodes it drives, for nbag independent bags: per bag a long pass (segments of
+ * long_distance metres, no overlap) and a short pass (short_distance, restarting overlap_distance
+ * before the cut), each cut online from the /true_odometry_to_init track exactly as
+ * subOdometryHandler does (distance from the previous sample, pubLocation = last sample within
+ * slam - overlap, laserOdometry reset through /control_command at every cut, ID:283-286,342-346),
+ * including the final rule that replays from the start of the previous segment when the rest is
+ * shorter than a third of the segment length (ID:366-414).  All 2 x nbag streams advance in lock
+ * step on the device.  Inputs as gpscal_loam_run_batched, with bag_sweep_off = nbag+1 sweep-index
+ * offsets.  Outputs (host arrays): per track its flag (0 long / 1 short, the IMTrack.track_flag of
+ * ID:347), bag, first / last replayed message (1-based within the bag), and rows
+ * track_off[k]..track_off[k+1] of track_xyzt = the IMLocalXYZT samples {x, y, z, t} (ID:80-88).
+ * Long tracks of all bags come first, then the short ones. */
+int gpscal_input_data_run(gpscal_ctx *ctx, int nbag, const float *xyz, const int *sweep_off,
+                          const int *bag_sweep_off, const double *stamps,
+                          double long_distance, double short_distance, double overlap_distance,
+                          int cap_tracks, int *track_flag, int *track_bag, int *seg_first,
+                          int *seg_last, int *track_off, double *track_xyzt, int cap_rows,
+                          int *ntracks_out, int corner_pool_cap, int surf_pool_cap);
+
 /* ------------------------------------------------------------- multi-GPU */
 /* New (no reference counterpart): the one exchange of the sharded pipeline,
  * an RCCL all-gather of per-segment pose chains / fit results over xGMI

@@ -192,6 +192,14 @@ void orc_assoc_to_map(const float sum[6], const float bef[6], const float aft[6]
 int orc_loam_run(const float *xyz, const int *sweep_off, int nsweeps, const double *stamps, float *lo_sum,
                  float *lm_aft, float *tm_mapped, double *track, int *lm_iters);
 
+/* input_data's replay + segmentation state machine (input_data.cpp:78-124, 266-444) around the
+ * node chain, one bag, one pass (long pass: overlap 0; short pass: overlap > 0).  Track k replays
+ * messages seg_first[k]..seg_last[k] (1-based) and holds rows track_off[k]..track_off[k+1] of
+ * track_xyzt ({x, y, z, t} as collected at ID:80-88).  Returns the number of tracks or -1. */
+int orc_input_data_pass(const float *xyz, const int *sweep_off, int nsweeps, const double *stamps, double slam_distance,
+                        double overlap, int cap_tracks, int *seg_first, int *seg_last, int *track_off,
+                        double *track_xyzt, int cap_rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -379,129 +379,281 @@ static void lm_step(lm_state *S, const cl *cornerLast, const cl *surfLast, const
     cl_free(&sMap);
 }
 
+/* ---- the node chain as a steppable object: one call per published sweep, and laserOdometry's
+ * /control_command reset (LO:411-415) between segments */
+typedef struct {
+    float transform[6], transformSum[6];
+    cl cornerLast, surfLast;
+    int lastNumC, lastNumS, frameCount, lo_inited;
+    lm_state *S;
+    cl *store;
+    float mSum[6], mIncre[6], mMapped[6], mBef[6], mAft[6];
+    double pre[4], tmpd[4];
+} chain;
+
+static chain *chain_new(void)
+{
+    chain *C = (chain *)calloc(1, sizeof(chain));
+    C->frameCount = 1; /* skipFrameNum, LO:495 */
+    C->S = (lm_state *)calloc(1, sizeof(lm_state));
+    C->store = (cl *)calloc(2 * LNUM, sizeof(cl));
+    for (int i = 0; i < LNUM; ++i) {
+        C->S->corner[i] = &C->store[i];
+        C->S->surf[i] = &C->store[LNUM + i];
+    }
+    C->S->inited = 0;
+    lm_reset(C->S);
+    return C;
+}
+
+static void chain_free(chain *C)
+{
+    for (int i = 0; i < 2 * LNUM; ++i) cl_free(&C->store[i]);
+    free(C->store);
+    free(C->S);
+    cl_free(&C->cornerLast);
+    cl_free(&C->surfLast);
+    free(C);
+}
+
+/* /control_command with systemInited = false (ID:283-286,327-330; LO:411-415) */
+static void chain_control_reset(chain *C) { C->lo_inited = 0; }
+
+/* one raw sweep through the four nodes.  Returns 1 when /true_odometry_to_init was published
+ * (track = {x, y, HEIGHT, stamp}), 0 for the sweep that (re)initialises laserOdometry. */
+static int chain_step(chain *C, const float *xyz, int n, double stamp, float *lo_sum, float *lm_aft,
+                      float *tm_mapped, double *track, int *lm_iters)
+{
+    const size_t cap = (size_t)4 * (n > 0 ? n : 1) + 16;
+    float *full = (float *)malloc(sizeof(float) * 4 * cap), *sharp = (float *)malloc(sizeof(float) * 4 * cap),
+          *lsharp = (float *)malloc(sizeof(float) * 4 * cap), *flat = (float *)malloc(sizeof(float) * 4 * cap),
+          *lflat = (float *)malloc(sizeof(float) * 4 * cap);
+    int nf, nsh, nls, nfl, nlf, published = 0;
+    orc_sr_extract(xyz, n, full, &nf, sharp, &nsh, lsharp, &nls, flat, &nfl, lflat, &nlf);
+    if (lm_aft)
+        for (int k = 0; k < 6; ++k) lm_aft[k] = NAN;
+    if (tm_mapped)
+        for (int k = 0; k < 6; ++k) tm_mapped[k] = NAN;
+    if (track)
+        for (int k = 0; k < 4; ++k) track[k] = NAN;
+    if (lm_iters) *lm_iters = -1;
+    if (!C->lo_inited) { /* LO:519-562: this sweep only seeds the "last" clouds */
+        C->cornerLast.n = C->surfLast.n = 0;
+        for (int i = 0; i < nls; ++i) cl_push(&C->cornerLast, lsharp + 4 * i);
+        for (int i = 0; i < nlf; ++i) cl_push(&C->surfLast, lflat + 4 * i);
+        for (int k = 0; k < 6; ++k) C->transform[k] = C->transformSum[k] = 0;
+        C->lastNumC = C->lastNumS = 0; /* LO:520-521: the counters are NOT set from the clouds here */
+        C->lo_inited = 1;
+        if (lo_sum) memcpy(lo_sum, C->transformSum, sizeof C->transformSum);
+    } else {
+        if (C->lastNumC > 10 && C->lastNumS > 100) { /* LO:571 */
+            float tr[6];
+            orc_lo_match(sharp, nsh, flat, nfl, C->cornerLast.p, C->cornerLast.n, C->surfLast.p, C->surfLast.n,
+                         C->transform, tr, NULL, NULL);
+            memcpy(C->transform, tr, sizeof tr);
+        }
+        float ns[6];
+        orc_lo_accumulate(C->transformSum, C->transform, ns); /* LO:1035-1066 */
+        memcpy(C->transformSum, ns, sizeof ns);
+        if (lo_sum) memcpy(lo_sum, C->transformSum, sizeof C->transformSum);
+        C->cornerLast.n = C->surfLast.n = 0; /* LO:1087-1114 */
+        float q[4];
+        for (int i = 0; i < nls; ++i) {
+            orc_lo_transform_to_end(C->transform, lsharp + 4 * i, q);
+            cl_push(&C->cornerLast, q);
+        }
+        for (int i = 0; i < nlf; ++i) {
+            orc_lo_transform_to_end(C->transform, lflat + 4 * i, q);
+            cl_push(&C->surfLast, q);
+        }
+        C->lastNumC = C->cornerLast.n;
+        C->lastNumS = C->surfLast.n;
+        ++C->frameCount;
+        int publish = C->frameCount >= 2; /* skipFrameNum + 1, LO:1126 */
+        if (publish) C->frameCount = 0;
+        /* ---- TM: laserOdometryHandler, TM:267-314 */
+        if (fabs((double)C->transformSum[3]) < 0.000001 && fabs((double)C->transformSum[4]) < 0.000001 &&
+            fabs((double)C->transformSum[5]) < 0.000001) {
+            C->pre[3] = 0;
+            for (int k = 0; k < 6; ++k) C->mSum[k] = C->mIncre[k] = C->mMapped[k] = C->mBef[k] = C->mAft[k] = 0;
+        }
+        memcpy(C->mSum, C->transformSum, sizeof C->mSum);
+        assoc_to_map(C->mSum, C->mBef, C->mAft, C->mIncre, C->mMapped);
+        if (tm_mapped) memcpy(tm_mapped, C->mMapped, sizeof C->mMapped);
+        { /* SaveTrailWithTimeTotxt, TM:113-157 */
+            double px = C->mMapped[5], py = C->mMapped[3], pz = C->mMapped[4];
+            double *pre = C->pre, *tmpd = C->tmpd;
+            if (pre[3] == 0) {
+                pre[0] = px;
+                pre[1] = py;
+                pre[2] = pz;
+                pre[3] = stamp;
+                memcpy(tmpd, pre, sizeof C->pre);
+            } else {
+                double dX = px - pre[0], dY = py - pre[1], dZ = pz - pre[2];
+                double dX1 = dX * sqrt(pow(dX, 2) + pow(dY, 2) + pow(dZ, 2)) / sqrt(pow(dX, 2) + pow(dY, 2));
+                double dY1 = dY * sqrt(pow(dX, 2) + pow(dY, 2) + pow(dZ, 2)) / sqrt(pow(dX, 2) + pow(dY, 2));
+                tmpd[0] += dX1;
+                tmpd[1] += dY1;
+                tmpd[2] = pz;
+                tmpd[3] = stamp;
+                pre[0] = px;
+                pre[1] = py;
+                pre[2] = pz;
+                pre[3] = stamp;
+            }
+            if (track) {
+                track[0] = tmpd[0];
+                track[1] = tmpd[1];
+                track[2] = 10.0; /* HEIGHT, common.h:16 */
+                track[3] = tmpd[3];
+            }
+            published = 1;
+        }
+        /* ---- LM: every (skipFrameNum+1)-th sweep */
+        if (publish) {
+            int it = 0;
+            lm_step(C->S, &C->cornerLast, &C->surfLast, C->transformSum, &it);
+            if (lm_aft) memcpy(lm_aft, C->S->tAft, sizeof C->S->tAft);
+            if (lm_iters) *lm_iters = it;
+            /* odomAftMappedHandler, TM:316-337 */
+            memcpy(C->mAft, C->S->tAft, sizeof C->mAft);
+            memcpy(C->mBef, C->S->tBef, sizeof C->mBef);
+        }
+    }
+    free(full);
+    free(sharp);
+    free(lsharp);
+    free(flat);
+    free(lflat);
+    return published;
+}
+
 int orc_loam_run(const float *xyz, const int *sweep_off, int nsweeps, const double *stamps, float *lo_sum,
                  float *lm_aft, float *tm_mapped, double *track, int *lm_iters)
 {
-    /* ---- LO state (LO:495-563) */
-    float transform[6] = {0, 0, 0, 0, 0, 0}, transformSum[6] = {0, 0, 0, 0, 0, 0};
-    cl cornerLast = {0, 0, 0}, surfLast = {0, 0, 0};
-    int lastNumC = 0, lastNumS = 0, frameCount = 1 /* skipFrameNum, LO:495 */;
-    /* ---- LM state */
-    lm_state *S = (lm_state *)calloc(1, sizeof(lm_state));
-    cl *store = (cl *)calloc(2 * LNUM, sizeof(cl));
-    for (int i = 0; i < LNUM; ++i) {
-        S->corner[i] = &store[i];
-        S->surf[i] = &store[LNUM + i];
-    }
-    S->inited = 0;
-    lm_reset(S);
-    /* ---- TM state (TM:100-101, file-scope zeros) */
-    float mSum[6] = {0}, mIncre[6] = {0}, mMapped[6] = {0}, mBef[6] = {0}, mAft[6] = {0};
-    double pre[4] = {0, 0, 0, 0}, tmpd[4] = {0, 0, 0, 0}; /* localX, localY, localZ, timestamp */
-
-    for (int t = 0; t < nsweeps; ++t) {
-        const int n = sweep_off[t + 1] - sweep_off[t];
-        const size_t cap = (size_t)4 * (n > 0 ? n : 1) + 16;
-        float *full = (float *)malloc(sizeof(float) * 4 * cap), *sharp = (float *)malloc(sizeof(float) * 4 * cap),
-              *lsharp = (float *)malloc(sizeof(float) * 4 * cap), *flat = (float *)malloc(sizeof(float) * 4 * cap),
-              *lflat = (float *)malloc(sizeof(float) * 4 * cap);
-        int nf, nsh, nls, nfl, nlf;
-        orc_sr_extract(xyz + 3 * (size_t)sweep_off[t], n, full, &nf, sharp, &nsh, lsharp, &nls, flat, &nfl, lflat, &nlf);
-        for (int k = 0; k < 6; ++k) {
-            lm_aft[6 * t + k] = NAN;
-            tm_mapped[6 * t + k] = NAN;
-        }
-        for (int k = 0; k < 4; ++k) track[4 * t + k] = NAN;
-        if (lm_iters) lm_iters[t] = -1;
-        if (t == 0) { /* LO:519-562: the first sweep only seeds the "last" clouds */
-            cornerLast.n = surfLast.n = 0;
-            for (int i = 0; i < nls; ++i) cl_push(&cornerLast, lsharp + 4 * i);
-            for (int i = 0; i < nlf; ++i) cl_push(&surfLast, lflat + 4 * i);
-            for (int k = 0; k < 6; ++k) transform[k] = transformSum[k] = 0;
-            lastNumC = lastNumS = 0; /* LO:520-521: the counters are NOT set from the clouds here */
-            memcpy(lo_sum + 6 * t, transformSum, sizeof transformSum);
-        } else {
-            if (lastNumC > 10 && lastNumS > 100) { /* LO:571 */
-                float tr[6];
-                orc_lo_match(sharp, nsh, flat, nfl, cornerLast.p, cornerLast.n, surfLast.p, surfLast.n, transform, tr,
-                             NULL, NULL);
-                memcpy(transform, tr, sizeof tr);
-            }
-            float ns[6];
-            orc_lo_accumulate(transformSum, transform, ns); /* LO:1035-1066 */
-            memcpy(transformSum, ns, sizeof ns);
-            memcpy(lo_sum + 6 * t, transformSum, sizeof transformSum);
-            cornerLast.n = surfLast.n = 0; /* LO:1087-1114 */
-            float q[4];
-            for (int i = 0; i < nls; ++i) {
-                orc_lo_transform_to_end(transform, lsharp + 4 * i, q);
-                cl_push(&cornerLast, q);
-            }
-            for (int i = 0; i < nlf; ++i) {
-                orc_lo_transform_to_end(transform, lflat + 4 * i, q);
-                cl_push(&surfLast, q);
-            }
-            lastNumC = cornerLast.n;
-            lastNumS = surfLast.n;
-            ++frameCount;
-            int publish = frameCount >= 2; /* skipFrameNum + 1, LO:1126 */
-            if (publish) frameCount = 0;
-            /* ---- TM: laserOdometryHandler, TM:267-314 */
-            if (fabs((double)transformSum[3]) < 0.000001 && fabs((double)transformSum[4]) < 0.000001 &&
-                fabs((double)transformSum[5]) < 0.000001) {
-                pre[3] = 0;
-                for (int k = 0; k < 6; ++k) mSum[k] = mIncre[k] = mMapped[k] = mBef[k] = mAft[k] = 0;
-            }
-            memcpy(mSum, transformSum, sizeof mSum);
-            assoc_to_map(mSum, mBef, mAft, mIncre, mMapped);
-            memcpy(tm_mapped + 6 * t, mMapped, sizeof mMapped);
-            { /* SaveTrailWithTimeTotxt, TM:113-157 */
-                double px = mMapped[5], py = mMapped[3], pz = mMapped[4];
-                if (pre[3] == 0) {
-                    pre[0] = px;
-                    pre[1] = py;
-                    pre[2] = pz;
-                    pre[3] = stamps[t];
-                    memcpy(tmpd, pre, sizeof pre);
-                } else {
-                    double dX = px - pre[0], dY = py - pre[1], dZ = pz - pre[2];
-                    double dX1 = dX * sqrt(pow(dX, 2) + pow(dY, 2) + pow(dZ, 2)) / sqrt(pow(dX, 2) + pow(dY, 2));
-                    double dY1 = dY * sqrt(pow(dX, 2) + pow(dY, 2) + pow(dZ, 2)) / sqrt(pow(dX, 2) + pow(dY, 2));
-                    tmpd[0] += dX1;
-                    tmpd[1] += dY1;
-                    tmpd[2] = pz;
-                    tmpd[3] = stamps[t];
-                    pre[0] = px;
-                    pre[1] = py;
-                    pre[2] = pz;
-                    pre[3] = stamps[t];
-                }
-                track[4 * t] = tmpd[0];
-                track[4 * t + 1] = tmpd[1];
-                track[4 * t + 2] = 10.0; /* HEIGHT, common.h:16 */
-                track[4 * t + 3] = tmpd[3];
-            }
-            /* ---- LM: every (skipFrameNum+1)-th sweep */
-            if (publish) {
-                int it = 0;
-                lm_step(S, &cornerLast, &surfLast, transformSum, &it);
-                memcpy(lm_aft + 6 * t, S->tAft, sizeof S->tAft);
-                if (lm_iters) lm_iters[t] = it;
-                /* odomAftMappedHandler, TM:316-337 */
-                memcpy(mAft, S->tAft, sizeof mAft);
-                memcpy(mBef, S->tBef, sizeof mBef);
-            }
-        }
-        free(full);
-        free(sharp);
-        free(lsharp);
-        free(flat);
-        free(lflat);
-    }
-    for (int i = 0; i < 2 * LNUM; ++i) cl_free(&store[i]);
-    free(store);
-    free(S);
-    cl_free(&cornerLast);
-    cl_free(&surfLast);
+    chain *C = chain_new();
+    for (int t = 0; t < nsweeps; ++t)
+        chain_step(C, xyz + 3 * (size_t)sweep_off[t], sweep_off[t + 1] - sweep_off[t], stamps[t], lo_sum + 6 * t,
+                   lm_aft + 6 * t, tm_mapped + 6 * t, track + 4 * t, lm_iters ? lm_iters + t : NULL);
+    chain_free(C);
     return 0;
+}
+
+/* =====================================================================
+ * input_data's replay + segmentation (ID = lidar_slam/input_data/input_data.cpp:78-124, 266-444)
+ * around the node chain, for ONE bag (a list of sweeps) and ONE pass (`times`): long pass =
+ * (slam_distance, overlap 0), short pass = (slam_distance, overlap > 0).  Emits the tracks
+ * input_data publishes on /slam_track, in order: seg_first[k] .. seg_last[k] are the 1-based
+ * message indices replayed for track k, track rows {x, y, z, t} as collected by
+ * subOdometryHandler (ID:80-88).  Returns the number of tracks (<= cap_tracks), or -1 when the
+ * row buffer is too small.
+ * ===================================================================== */
+int orc_input_data_pass(const float *xyz, const int *sweep_off, int nsweeps, const double *stamps, double slam_distance,
+                        double overlap, int cap_tracks, int *seg_first, int *seg_last, int *track_off,
+                        double *track_xyzt, int cap_rows)
+{
+    typedef struct {
+        int idx;
+        double distance, timestamp;
+    } loc;
+    chain *C = chain_new();
+    loc *all = (loc *)malloc(sizeof(loc) * (size_t)(nsweeps + 4));
+    int nall = 0, ntracks = 0, nrows = 0;
+    loc pub = {0, 0, 0};
+    all[nall++] = pub; /* ID:269-273 */
+    double total = 0;
+    /* the two most recent tracks are still queued when the replay ends (ID:348-352) */
+    int cursor = 0; /* messages published so far in file order = the next message index - 1 */
+    int have_pre = 0;
+    double prex = 0, prey = 0, prez = 0;
+    chain_control_reset(C); /* ID:283-286 */
+    track_off[0] = 0;
+#define EMIT_BEGIN(first)            \
+    do {                             \
+        if (ntracks >= cap_tracks) { \
+            ntracks = -1;            \
+            goto done;               \
+        }                            \
+        seg_first[ntracks] = (first); \
+    } while (0)
+    int exhausted = 0;
+    while (!exhausted) { /* ID:288 */
+        int end = 0;
+        EMIT_BEGIN(pub.idx + 1);
+        int last_msg = pub.idx;
+        for (int i = pub.idx + 1; i <= nsweeps; ++i) { /* ID:311-340: messages after pubLocation */
+            double tr[4];
+            last_msg = i;
+            int got = chain_step(C, xyz + 3 * (size_t)sweep_off[i - 1], sweep_off[i] - sweep_off[i - 1], stamps[i - 1],
+                                 NULL, NULL, NULL, tr, NULL);
+            if (got) { /* subOdometryHandler, ID:78-118 */
+                if (nrows >= cap_rows) {
+                    ntracks = -1;
+                    goto done;
+                }
+                memcpy(track_xyzt + 4 * (size_t)nrows, tr, sizeof tr);
+                ++nrows;
+                loc t;
+                t.idx = i;
+                t.distance = have_pre ? sqrt(pow(tr[0] - prex, 2) + pow(tr[1] - prey, 2) + pow(tr[2] - prez, 2)) + total : 0;
+                t.timestamp = tr[3];
+                have_pre = 1;
+                prex = tr[0];
+                prey = tr[1];
+                prez = tr[2];
+                if (t.distance <= slam_distance - overlap) pub = t;
+                else if (all[nall - 1].timestamp != pub.timestamp) all[nall++] = pub;
+                total = t.distance;
+            }
+            if (total > slam_distance) { /* ID:332-339 */
+                total = 0;
+                end = 1;
+                break;
+            }
+        }
+        if (end) chain_control_reset(C); /* ID:342-346 */
+        else exhausted = 1;
+        seg_last[ntracks] = last_msg;
+        ++ntracks;
+        track_off[ntracks] = nrows;
+        have_pre = 0; /* preOdometry = NULL, ID:351 */
+        cursor = last_msg;
+        if (pub.idx >= nsweeps) exhausted = 1;
+    }
+    (void)cursor;
+    /* the rest is too short: replay from the start of the previous track to the end (ID:366-414) */
+    if (nall > 1 && total < slam_distance / 3.0 /* IMREST */) {
+        loc tmp = all[nall - 2];
+        /* the queue holds the last two tracks (or one): they are dropped (ID:377-381) */
+        int drop = ntracks >= 2 ? 2 : ntracks;
+        ntracks -= drop;
+        nrows = track_off[ntracks];
+        chain_control_reset(C);
+        EMIT_BEGIN(tmp.idx + 1);
+        int last_msg = tmp.idx;
+        for (int i = tmp.idx + 1; i <= nsweeps; ++i) {
+            double tr[4];
+            last_msg = i;
+            int got = chain_step(C, xyz + 3 * (size_t)sweep_off[i - 1], sweep_off[i] - sweep_off[i - 1], stamps[i - 1],
+                                 NULL, NULL, NULL, tr, NULL);
+            if (got) {
+                if (nrows >= cap_rows) {
+                    ntracks = -1;
+                    goto done;
+                }
+                memcpy(track_xyzt + 4 * (size_t)nrows, tr, sizeof tr);
+                ++nrows;
+            }
+        }
+        seg_last[ntracks] = last_msg;
+        if (nrows > track_off[ntracks]) { /* ID:419-424: only a non-empty track is queued */
+            ++ntracks;
+            track_off[ntracks] = nrows;
+        }
+    }
+done:
+    free(all);
+    chain_free(C);
+    return ntracks;
 }

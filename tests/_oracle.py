@@ -343,3 +343,23 @@ def loam_run(sweeps, stamps):
     lib().orc_loam_run(_p(xyz, c_fp), _p(off, C.POINTER(C.c_int)), ns, _p(stamps, c_dp), _p(lo, c_fp), _p(lm, c_fp),
                        _p(tm, c_fp), _p(track, c_dp), _p(iters, C.POINTER(C.c_int)))
     return {"lo_sum": lo, "lm_aft": lm, "tm_mapped": tm, "track": track, "lm_iters": iters}
+
+
+def input_data_pass(sweeps, stamps, slam_distance, overlap):
+    """input_data's replay + segmentation around the LOAM chain (one bag, one pass)."""
+    ns = len(sweeps)
+    off = np.zeros(ns + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(a) for a in sweeps])
+    xyz = np.ascontiguousarray(np.concatenate(sweeps), dtype=np.float32)
+    stamps = np.ascontiguousarray(stamps, dtype=np.float64)
+    cap_t, cap_r = ns + 4, 4 * ns + 16
+    first = np.zeros(cap_t, dtype=np.int32)
+    last = np.zeros(cap_t, dtype=np.int32)
+    toff = np.zeros(cap_t + 1, dtype=np.int32)
+    rows = np.zeros((cap_r, 4), dtype=np.float64)
+    ip = C.POINTER(C.c_int)
+    nt = lib().orc_input_data_pass(_p(xyz, c_fp), _p(off, ip), ns, _p(stamps, c_dp), C.c_double(slam_distance),
+                                   C.c_double(overlap), cap_t, _p(first, ip), _p(last, ip), _p(toff, ip),
+                                   _p(rows, c_dp), cap_r)
+    assert nt >= 0
+    return [{"first": int(first[k]), "last": int(last[k]), "track": rows[toff[k]:toff[k + 1]].copy()} for k in range(nt)]

@@ -65,3 +65,30 @@ def test_loam_run_ring_shift(ctx):
     ref = O.loam_run(sw, st)
     _check(got, ref, 24)
     assert ref["tm_mapped"][-1][5] > 40.0  # forward is LOAM's z
+
+
+def test_input_data_segmentation_matches_oracle(ctx):
+    """input_data.cpp:78-124, 266-444: both passes of two bags, cut online from the device track.
+    The cuts (first / last replayed message of every track) must equal the oracle's exactly; the
+    samples agree to 2e-2 m like the chain itself."""
+    W = synth.lidar_world(0, length=600.0)
+    bag_a, st_a, _ = synth.drive(W, 70, seed=1, n_az=900)
+    bag_b, st_b, _ = synth.drive(W, 40, seed=7, n_az=900, start=(200.0, -1.0), speed=6.0)
+    L, S, OV = 30.0, 14.0, 5.0
+    got = ctx.input_data_run([bag_a, bag_b], [st_a, st_b], L, S, OV, corner_pool_cap=1 << 16, surf_pool_cap=1 << 18)
+    ref = []
+    for flag, (dist, ov) in enumerate(((L, 0.0), (S, OV))):
+        for b, (bag, st) in enumerate(((bag_a, st_a), (bag_b, st_b))):
+            for t in O.input_data_pass(bag, st, dist, ov):
+                ref.append(dict(t, flag=flag, bag=b))
+    assert [(t["flag"], t["bag"], t["first"], t["last"]) for t in got] == \
+           [(t["flag"], t["bag"], t["first"], t["last"]) for t in ref]
+    for g, r in zip(got, ref):
+        assert g["track"].shape == r["track"].shape
+        assert np.abs(g["track"][:, :2] - r["track"][:, :2]).max() < 2e-2
+        assert np.array_equal(g["track"][:, 2:], r["track"][:, 2:])
+    # several long and short tracks, overlapping replays in the short pass
+    longs = [t for t in ref if t["flag"] == 0 and t["bag"] == 0]
+    shorts = [t for t in ref if t["flag"] == 1 and t["bag"] == 0]
+    assert len(longs) >= 2 and len(shorts) >= 3
+    assert any(b["first"] <= a["last"] - 2 for a, b in zip(shorts, shorts[1:]))

@@ -378,3 +378,27 @@ def test_voxel_grid_oracle_is_a_centroid_filter():
     far = np.array([[0, 0, 0, 1], [1e5, 1e5, 1e5, 2]], dtype=np.float32)
     out, rc = O.voxel_grid(far, 0.2)
     assert rc == 1 and np.array_equal(out, far)
+
+
+def test_input_data_oracle_cuts_tracks_by_distance():
+    """input_data.cpp:78-124, 266-444 restated around the node chain: tracks are cut when the travelled
+    distance exceeds the segment length, the next one restarts after the last sample within
+    length - overlap, and the first message after every restart publishes no odometry (LO:519-562)."""
+    from gpscalibration_amd import synth
+    W = synth.lidar_world(0, length=600.0)
+    sw, st, _ = synth.drive(W, 60, seed=1, n_az=450)
+    longs = O.input_data_pass(sw, st, 25.0, 0.0)
+    shorts = O.input_data_pass(sw, st, 12.0, 4.0)
+    for tracks, length, ov in ((longs, 25.0, 0.0), (shorts, 12.0, 4.0)):
+        assert tracks[0]["first"] == 1 and tracks[-1]["last"] == 60
+        for a, b in zip(tracks, tracks[1:]):
+            assert a["first"] < b["first"] <= a["last"]  # restart inside the previous track
+        for t in tracks:
+            n_msgs = t["last"] - t["first"] + 1
+            assert len(t["track"]) == n_msgs - 1  # the restarting message has no odometry
+            d = np.hypot(np.diff(t["track"][:, 0]), np.diff(t["track"][:, 1])).sum()
+            assert d < length + 3.0  # cut right after the crossing sample
+            assert np.all(t["track"][:, 2] == 10.0) and np.all(np.diff(t["track"][:, 3]) > 0)
+    assert len(shorts) > len(longs) >= 2
+    # short tracks overlap by roughly the overlap distance
+    assert any(b["first"] < a["last"] for a, b in zip(shorts, shorts[1:]))
