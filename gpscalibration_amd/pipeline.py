@@ -22,6 +22,9 @@ def load_host():
         _H.gpscal_host_pipeline.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p,
                                             C.c_void_p]
+        _H.gpscal_host_pipeline_sweeps.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_double, C.c_double, C.c_double, C.c_char_p, C.c_int, C.c_char_p,
+                                                   C.c_char_p, C.c_void_p, C.c_void_p]
     return _H
 
 
@@ -44,3 +47,27 @@ def run_tracks(gps_log_path, longs, shorts, method="UTM", band_type=3, kml_origi
     if rc != 0:
         raise RuntimeError("gpscal_host_pipeline failed (%d)" % rc)
     return {"seconds": sec.tolist(), "points": npts.tolist()}
+
+
+def run_sweeps(gps_log_path, bags, stamps, long_distance, short_distance, overlap_distance, method="UTM",
+               band_type=3, kml_original="", kml_calibrated=""):
+    """Raw sweeps -> KML: input_data's replay + segmentation with the LOAM nodes on the GPU, then the
+    track pipeline.  `bags` = list of lists of [n,3] float32 sweeps.  Returns dict(seconds=[slam, long,
+    short, output, total], counts=[long tracks, short tracks, gps points, calibrated points])."""
+    H = load_host()
+    flat = [sw for b in bags for sw in b]
+    bag_off = np.zeros(len(bags) + 1, dtype=np.int32)
+    bag_off[1:] = np.cumsum([len(b) for b in bags])
+    off = np.zeros(len(flat) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(a) for a in flat])
+    xyz = np.ascontiguousarray(np.concatenate(flat), dtype=np.float32)
+    st = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64) for x in stamps]))
+    sec = np.zeros(5)
+    cnt = np.zeros(4, dtype=np.int32)
+    rc = H.gpscal_host_pipeline_sweeps(gps_log_path.encode(), len(bags), xyz.ctypes.data, off.ctypes.data,
+                                       bag_off.ctypes.data, st.ctypes.data, float(long_distance), float(short_distance),
+                                       float(overlap_distance), method.encode(), band_type, kml_original.encode(),
+                                       kml_calibrated.encode(), sec.ctypes.data, cnt.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("gpscal_host_pipeline_sweeps failed (%d)" % rc)
+    return {"seconds": sec.tolist(), "counts": cnt.tolist()}

@@ -400,3 +400,39 @@ def drive(world, nsweeps, seed=0, speed=8.0, n_az=900, start=(0.0, 0.0), yaw0=0.
         yaw += yaw_rate * period
     stamps = 1494650700.0 + period * np.arange(nsweeps)
     return sweeps, stamps, np.array(truth)
+
+
+def gprmc_for_path(stamps, xy, seed=0, sigma=1.5, origin=(3450164.0, 400633250.0)):
+    """A 1 Hz GPRMC log for a path given in local metres (x along the street = north, y = -east ...
+    any rigid placement does: the calibration solves for it).  The path is placed at `origin` in the
+    reference's UTM-like plane (northing, easting + band offset) and converted with the inverse
+    series the reference uses (gps_process.cc:1010-1058) through the CPU restatement's twin in numpy:
+    here a plain inverse transverse Mercator, good to centimetres, is enough for test input."""
+    rng = np.random.default_rng(seed)
+    t0, t1 = math.floor(stamps[0]) - 1, math.ceil(stamps[-1]) + 1
+    ts = np.arange(t0, t1 + 1, 1.0)
+    x = np.interp(ts, stamps, xy[:, 0]) + rng.normal(0, sigma, len(ts))
+    y = np.interp(ts, stamps, xy[:, 1]) + rng.normal(0, sigma, len(ts))
+    north = origin[0] + x
+    east = origin[1] + y
+    band = math.floor(float(east[0]) / 1e7)
+    e = east - band * 1e7 - 5e5
+    lon0 = math.radians(band * 3.0)
+    a, f, k0 = 6378137.0, 1 / 298.257223563, 0.9996
+    e2 = f * (2 - f)
+    lines = []
+    for i in range(len(ts)):
+        m = north[i] / k0
+        mu = m / (a * (1 - e2 / 4 - 3 * e2 ** 2 / 64 - 5 * e2 ** 3 / 256))
+        e1 = (1 - math.sqrt(1 - e2)) / (1 + math.sqrt(1 - e2))
+        p1 = (mu + (3 * e1 / 2 - 27 * e1 ** 3 / 32) * math.sin(2 * mu) + (21 * e1 ** 2 / 16 - 55 * e1 ** 4 / 32) * math.sin(4 * mu)
+              + (151 * e1 ** 3 / 96) * math.sin(6 * mu))
+        n1 = a / math.sqrt(1 - e2 * math.sin(p1) ** 2)
+        t1_ = math.tan(p1) ** 2
+        c1 = e2 / (1 - e2) * math.cos(p1) ** 2
+        r1 = a * (1 - e2) / (1 - e2 * math.sin(p1) ** 2) ** 1.5
+        d = e[i] / (n1 * k0)
+        lat = p1 - (n1 * math.tan(p1) / r1) * (d * d / 2 - (5 + 3 * t1_ + 10 * c1 - 4 * c1 * c1 - 9 * e2 / (1 - e2)) * d ** 4 / 24)
+        lon = lon0 + (d - (1 + 2 * t1_ + c1) * d ** 3 / 6) / math.cos(p1)
+        lines.append(gprmc_line(ts[i], math.degrees(lat), math.degrees(lon), True))
+    return "\n\n".join(lines) + "\n\n"  # the shipped log separates fixes by an empty line

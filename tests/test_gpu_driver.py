@@ -78,3 +78,34 @@ def test_driver_rejects_bad_arguments(tmp_path):
     r = subprocess.run([RUN, "--gps_input_filename", "x", "--slam_track_filename", "y", "--ctm", "Mercator"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
     assert r.returncode != 0 and "UTM/Gaussion" in r.stdout
+
+
+def test_raw_sweeps_to_kml_matches_oracle(tmp_path):
+    """The whole product path from raw lidar sweeps: input_data's replay + segmentation and the four
+    LOAM nodes on the GPU (gpscal_input_data_run), then the long / short track nodes and the KML
+    writer -- against the oracle chain on the same synthetic drive and GPRMC log.  KML coordinates
+    within 1e-6 degrees (north_star's bar; measured ~1e-8: the LOAM tracks differ by < 1 mm)."""
+    from gpscalibration_amd import pipeline
+    W = synth.lidar_world(0, length=600.0)
+    bag, st, truth = synth.drive(W, 150, seed=1, n_az=900)
+    gprmc = synth.gprmc_for_path(st, truth[:, :2], seed=3, sigma=1.0)
+    log = tmp_path / "gps.txt"
+    log.write_text(gprmc)
+    k0, k1 = tmp_path / "ori.kml", tmp_path / "cal.kml"
+    L, S, OV = 50.0, 22.0, 8.0
+    r = pipeline.run_sweeps(str(log), [bag], [st], L, S, OV, kml_original=str(k0), kml_calibrated=str(k1))
+    longs = [t["track"] for t in O.input_data_pass(bag, st, L, 0.0) if len(t["track"])]
+    shorts = [t["track"] for t in O.input_data_pass(bag, st, S, OV) if len(t["track"])]
+    assert r["counts"][:2] == [len(longs), len(shorts)] and len(longs) >= 2 and len(shorts) >= 4
+    gps, acc = _oracle_run(longs, shorts, gprmc)
+    ll0, alt0 = O.local_to_wgs(gps)
+    ll1, alt1 = O.local_to_wgs(acc)
+    end1, rgb1 = O.colour_segments(acc)
+    c0, c1 = _kml_coords(k0.read_text()), _kml_coords(k1.read_text())
+    r0, r1 = _kml_coords(O.kml(ll0, alt0, 0)), _kml_coords(O.kml(ll1, alt1, 1, end1, rgb1))
+    assert c0.shape == r0.shape and c1.shape == r1.shape and len(c1) > 100
+    assert np.abs(c0 - r0).max() < 1e-6
+    assert np.abs(c1 - r1).max() < 1e-6
+    # and the calibrated track is a sensible answer: within a few metres of the true path's GPS fixes
+    lat, lon, _ = O.parse_gprmc(gprmc, st[0], st[-1])
+    assert abs(c1[:, 1].mean() - np.mean(lat)) < 1e-3 and abs(c1[:, 0].mean() - np.mean(lon)) < 1e-3
