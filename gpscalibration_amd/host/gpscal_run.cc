@@ -93,10 +93,66 @@ std::vector<Track> cut_segments(const Track &chain, double dist, double overlap)
     return out;
 }
 
+// Sweep file (stand-in for rosbag files, which this build does not read yet): "GPSW1\n", int32
+// nbag, then per bag int32 nsweeps and per sweep { double stamp; int32 npoints; float xyz[3*npoints] }.
+bool slam_tracks_from_sweeps(const std::string &path, double L, double S, double OV, std::vector<Track> &longs,
+                             std::vector<Track> &shorts)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) {
+        fprintf(stderr, "open %s error\n", path.c_str());
+        return false;
+    }
+    char magic[6] = {0};
+    int nbag = 0;
+    bool ok = fread(magic, 1, 6, f) == 6 && memcmp(magic, "GPSW1\n", 6) == 0 && fread(&nbag, 4, 1, f) == 1 && nbag > 0;
+    std::vector<float> xyz;
+    std::vector<int> sweep_off(1, 0), bag_off(1, 0);
+    std::vector<double> stamps;
+    for (int b = 0; ok && b < nbag; ++b) {
+        int ns = 0;
+        ok = fread(&ns, 4, 1, f) == 1 && ns >= 0;
+        for (int k = 0; ok && k < ns; ++k) {
+            double t;
+            int n;
+            ok = fread(&t, 8, 1, f) == 1 && fread(&n, 4, 1, f) == 1 && n >= 0;
+            if (!ok) break;
+            const size_t at = xyz.size();
+            xyz.resize(at + (size_t)3 * n);
+            ok = n == 0 || fread(xyz.data() + at, 12, (size_t)n, f) == (size_t)n;
+            stamps.push_back(t);
+            sweep_off.push_back(sweep_off.back() + n);
+        }
+        bag_off.push_back((int)stamps.size());
+    }
+    fclose(f);
+    if (!ok || stamps.empty()) {
+        fprintf(stderr, "%s is not a sweep file\n", path.c_str());
+        return false;
+    }
+    const int nsw = (int)stamps.size();
+    const int cap_t = 2 * nsw + 8, cap_r = 8 * nsw + 16;
+    std::vector<int> flag(cap_t), bag(cap_t), first(cap_t), last(cap_t), toff(cap_t + 1);
+    std::vector<double> rows((size_t)cap_r * 4);
+    int nt = 0;
+    gpscal_host::check(gpscal_input_data_run(gpscal_host::default_ctx(), nbag, xyz.data(), sweep_off.data(),
+                                             bag_off.data(), stamps.data(), L, S, OV, cap_t, flag.data(), bag.data(),
+                                             first.data(), last.data(), toff.data(), rows.data(), cap_r, &nt, 0, 0),
+                       "gpscal_input_data_run");
+    for (int k = 0; k < nt; ++k) {
+        const COORDXYZT *p = reinterpret_cast<const COORDXYZT *>(rows.data()) + toff[k];
+        Track v(p, p + (toff[k + 1] - toff[k]));
+        if (v.empty()) continue;
+        (flag[k] == 0 ? longs : shorts).push_back(v);
+    }
+    printf("SLAM Track Calculation Over\n");  // input_data.cpp:442
+    return true;
+}
+
 void usage()
 {
     fprintf(stderr,
-            "usage: gpscal_run --gps_input_filename LOG (--slam_track_filename FILE | --pose_chain FILE)\n"
+            "usage: gpscal_run --gps_input_filename LOG (--slam_track_filename FILE | --pose_chain FILE | --sweeps FILE)\n"
             "       [--gps_original_filename out.kml] [--gps_improved_filename out.kml] [--result_control 1]\n"
             "       [--total_long_distance 1000] [--total_short_distance 300] [--overlap_distance 100]\n"
             "       [--ctm UTM|Gaussion] [--gdt 3|6] [--kml_config src/gpsCalibration/config/kml_config.xml]\n");
@@ -122,7 +178,8 @@ int main(int argc, char **argv)
         }
         a[argv[i] + 2] = argv[i + 1];
     }
-    if (!a.count("gps_input_filename") || (!a.count("slam_track_filename") && !a.count("pose_chain"))) {
+    if (!a.count("gps_input_filename") ||
+        (!a.count("slam_track_filename") && !a.count("pose_chain") && !a.count("sweeps"))) {
         usage();
         return -1;
     }
@@ -142,6 +199,13 @@ int main(int argc, char **argv)
                 fprintf(stderr, "open %s error\n", a["slam_track_filename"].c_str());
                 return -1;
             }
+        } else if (a.count("sweeps")) {
+            // raw lidar sweeps (the bags' /velodyne_points): input_data's replay + segmentation and the
+            // four LOAM nodes run on the device, the tracks come back as /slam_track would carry them
+            if (!slam_tracks_from_sweeps(a["sweeps"], atof(a["total_long_distance"].c_str()),
+                                         atof(a["total_short_distance"].c_str()), atof(a["overlap_distance"].c_str()),
+                                         longs, shorts))
+                return -1;
         } else {
             Track chain;
             if (!read_chain(a["pose_chain"], chain)) {

@@ -436,3 +436,18 @@ def gprmc_for_path(stamps, xy, seed=0, sigma=1.5, origin=(3450164.0, 400633250.0
         lon = lon0 + (d - (1 + 2 * t1_ + c1) * d ** 3 / 6) / math.cos(p1)
         lines.append(gprmc_line(ts[i], math.degrees(lat), math.degrees(lon), True))
     return "\n\n".join(lines) + "\n\n"  # the shipped log separates fixes by an empty line
+
+
+def write_sweep_file(path, bags, stamps):
+    """gpscal_run --sweeps input: "GPSW1\\n", int32 nbag, per bag int32 nsweeps, per sweep
+    { float64 stamp; int32 npoints; float32 xyz[3 * npoints] }."""
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"GPSW1\n")
+        f.write(struct.pack("<i", len(bags)))
+        for bag, st in zip(bags, stamps):
+            f.write(struct.pack("<i", len(bag)))
+            for sw, t in zip(bag, st):
+                sw = np.ascontiguousarray(sw, dtype=np.float32)
+                f.write(struct.pack("<di", float(t), len(sw)))
+                f.write(sw.tobytes())

@@ -106,6 +106,15 @@ def test_raw_sweeps_to_kml_matches_oracle(tmp_path):
     assert c0.shape == r0.shape and c1.shape == r1.shape and len(c1) > 100
     assert np.abs(c0 - r0).max() < 1e-6
     assert np.abs(c1 - r1).max() < 1e-6
+    # the command-line driver gives the same files from a sweep file (run.sh's surface, no ROS)
+    swf, k2, k3 = tmp_path / "sweeps.bin", tmp_path / "ori2.kml", tmp_path / "cal2.kml"
+    synth.write_sweep_file(str(swf), [bag], [st])
+    p = subprocess.run([RUN, "--gps_input_filename", str(log), "--sweeps", str(swf), "--gps_original_filename", str(k2),
+                        "--gps_improved_filename", str(k3), "--total_long_distance", str(L), "--total_short_distance",
+                        str(S), "--overlap_distance", str(OV), "--kml_config", "/nonexistent"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout
+    assert k2.read_text() == k0.read_text() and k3.read_text() == k1.read_text()
     # and the calibrated track is a sensible answer: within a few metres of the true path's GPS fixes
     lat, lon, _ = O.parse_gprmc(gprmc, st[0], st[-1])
     assert abs(c1[:, 1].mean() - np.mean(lat)) < 1e-3 and abs(c1[:, 0].mean() - np.mean(lon)) < 1e-3
