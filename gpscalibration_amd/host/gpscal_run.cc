@@ -21,6 +21,7 @@
 #include <string>
 
 #include "gps_process.h"
+#include "rosbag_reader.h"
 #include "track_process.h"
 
 namespace {
@@ -93,50 +94,22 @@ std::vector<Track> cut_segments(const Track &chain, double dist, double overlap)
     return out;
 }
 
-// Sweep file (stand-in for rosbag files, which this build does not read yet): "GPSW1\n", int32
-// nbag, then per bag int32 nsweeps and per sweep { double stamp; int32 npoints; float xyz[3*npoints] }.
-bool slam_tracks_from_sweeps(const std::string &path, double L, double S, double OV, std::vector<Track> &longs,
-                             std::vector<Track> &shorts)
+// SLAM tracks of one replayed cloud series: input_data's replay + segmentation and the four LOAM
+// nodes on the device; the tracks come back as /slam_track would carry them.
+bool slam_tracks_from_series(const gpscal_host::CloudSeries &C, int nbag, const std::vector<int> &bag_off, double L,
+                             double S, double OV, std::vector<Track> &longs, std::vector<Track> &shorts)
 {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) {
-        fprintf(stderr, "open %s error\n", path.c_str());
+    const int nsw = (int)C.stamps.size();
+    if (nsw < 1) {
+        fprintf(stderr, "no lidar sweeps to replay\n");
         return false;
     }
-    char magic[6] = {0};
-    int nbag = 0;
-    bool ok = fread(magic, 1, 6, f) == 6 && memcmp(magic, "GPSW1\n", 6) == 0 && fread(&nbag, 4, 1, f) == 1 && nbag > 0;
-    std::vector<float> xyz;
-    std::vector<int> sweep_off(1, 0), bag_off(1, 0);
-    std::vector<double> stamps;
-    for (int b = 0; ok && b < nbag; ++b) {
-        int ns = 0;
-        ok = fread(&ns, 4, 1, f) == 1 && ns >= 0;
-        for (int k = 0; ok && k < ns; ++k) {
-            double t;
-            int n;
-            ok = fread(&t, 8, 1, f) == 1 && fread(&n, 4, 1, f) == 1 && n >= 0;
-            if (!ok) break;
-            const size_t at = xyz.size();
-            xyz.resize(at + (size_t)3 * n);
-            ok = n == 0 || fread(xyz.data() + at, 12, (size_t)n, f) == (size_t)n;
-            stamps.push_back(t);
-            sweep_off.push_back(sweep_off.back() + n);
-        }
-        bag_off.push_back((int)stamps.size());
-    }
-    fclose(f);
-    if (!ok || stamps.empty()) {
-        fprintf(stderr, "%s is not a sweep file\n", path.c_str());
-        return false;
-    }
-    const int nsw = (int)stamps.size();
     const int cap_t = 2 * nsw + 8, cap_r = 8 * nsw + 16;
     std::vector<int> flag(cap_t), bag(cap_t), first(cap_t), last(cap_t), toff(cap_t + 1);
     std::vector<double> rows((size_t)cap_r * 4);
     int nt = 0;
-    gpscal_host::check(gpscal_input_data_run(gpscal_host::default_ctx(), nbag, xyz.data(), sweep_off.data(),
-                                             bag_off.data(), stamps.data(), L, S, OV, cap_t, flag.data(), bag.data(),
+    gpscal_host::check(gpscal_input_data_run(gpscal_host::default_ctx(), nbag, C.xyz.data(), C.sweep_off.data(),
+                                             bag_off.data(), C.stamps.data(), L, S, OV, cap_t, flag.data(), bag.data(),
                                              first.data(), last.data(), toff.data(), rows.data(), cap_r, &nt, 0, 0),
                        "gpscal_input_data_run");
     for (int k = 0; k < nt; ++k) {
@@ -149,10 +122,82 @@ bool slam_tracks_from_sweeps(const std::string &path, double L, double S, double
     return true;
 }
 
+// Sweep file (a plain container for tests): "GPSW1\n", int32 nbag, then per bag int32 nsweeps and
+// per sweep { double stamp; int32 npoints; float xyz[3*npoints] }.
+bool slam_tracks_from_sweeps(const std::string &path, double L, double S, double OV, std::vector<Track> &longs,
+                             std::vector<Track> &shorts)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) {
+        fprintf(stderr, "open %s error\n", path.c_str());
+        return false;
+    }
+    char magic[6] = {0};
+    int nbag = 0;
+    bool ok = fread(magic, 1, 6, f) == 6 && memcmp(magic, "GPSW1\n", 6) == 0 && fread(&nbag, 4, 1, f) == 1 && nbag > 0;
+    gpscal_host::CloudSeries C;
+    C.sweep_off.push_back(0);
+    std::vector<int> bag_off(1, 0);
+    for (int b = 0; ok && b < nbag; ++b) {
+        int ns = 0;
+        ok = fread(&ns, 4, 1, f) == 1 && ns >= 0;
+        for (int k = 0; ok && k < ns; ++k) {
+            double t;
+            int n;
+            ok = fread(&t, 8, 1, f) == 1 && fread(&n, 4, 1, f) == 1 && n >= 0;
+            if (!ok) break;
+            const size_t at = C.xyz.size();
+            C.xyz.resize(at + (size_t)3 * n);
+            ok = n == 0 || fread(C.xyz.data() + at, 12, (size_t)n, f) == (size_t)n;
+            C.stamps.push_back(t);
+            C.sweep_off.push_back(C.sweep_off.back() + n);
+        }
+        bag_off.push_back((int)C.stamps.size());
+    }
+    fclose(f);
+    if (!ok || C.stamps.empty()) {
+        fprintf(stderr, "%s is not a sweep file\n", path.c_str());
+        return false;
+    }
+    return slam_tracks_from_series(C, nbag, bag_off, L, S, OV, longs, shorts);
+}
+
+// run.sh's bag_input_filename: a text file with one bag path per line (input_data.cpp:120-150); the
+// bags are replayed one after the other as ONE message sequence (segments may span bags, ID:296-345).
+bool slam_tracks_from_bags(const std::string &list, const std::string &topic, double L, double S, double OV,
+                           std::vector<Track> &longs, std::vector<Track> &shorts)
+{
+    std::ifstream in(list.c_str());
+    if (!in) {
+        fprintf(stderr, "ERROR: open %s error,please check it\n", list.c_str());  // input_data.cpp:127
+        return false;
+    }
+    gpscal_host::CloudSeries C;
+    C.sweep_off.push_back(0);
+    std::string line, err;
+    int nbags = 0;
+    while (std::getline(in, line)) {
+        while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back();
+        if (line.empty()) continue;
+        if (!gpscal_host::read_bag_clouds(line, topic, C, err)) {
+            fprintf(stderr, "ERROR: %s\n", err.c_str());
+            return false;
+        }
+        ++nbags;
+    }
+    if (nbags == 0) {
+        fprintf(stderr, "WARN:%s is NULL,please check it.\n", list.c_str());  // input_data.cpp:146
+        return false;
+    }
+    const std::vector<int> bag_off = {0, (int)C.stamps.size()};
+    return slam_tracks_from_series(C, 1, bag_off, L, S, OV, longs, shorts);
+}
+
 void usage()
 {
     fprintf(stderr,
-            "usage: gpscal_run --gps_input_filename LOG (--slam_track_filename FILE | --pose_chain FILE | --sweeps FILE)\n"
+            "usage: gpscal_run --gps_input_filename LOG (--bag_input_filename LIST | --sweeps FILE |\n"
+            "                  --slam_track_filename FILE | --pose_chain FILE)\n"
             "       [--gps_original_filename out.kml] [--gps_improved_filename out.kml] [--result_control 1]\n"
             "       [--total_long_distance 1000] [--total_short_distance 300] [--overlap_distance 100]\n"
             "       [--ctm UTM|Gaussion] [--gdt 3|6] [--kml_config src/gpsCalibration/config/kml_config.xml]\n");
@@ -179,7 +224,8 @@ int main(int argc, char **argv)
         a[argv[i] + 2] = argv[i + 1];
     }
     if (!a.count("gps_input_filename") ||
-        (!a.count("slam_track_filename") && !a.count("pose_chain") && !a.count("sweeps"))) {
+        (!a.count("slam_track_filename") && !a.count("pose_chain") && !a.count("sweeps") &&
+         !a.count("bag_input_filename"))) {
         usage();
         return -1;
     }
@@ -199,6 +245,12 @@ int main(int argc, char **argv)
                 fprintf(stderr, "open %s error\n", a["slam_track_filename"].c_str());
                 return -1;
             }
+        } else if (a.count("bag_input_filename")) {
+            // run.sh's own input: the list of rosbag files with the /velodyne_points clouds
+            if (!slam_tracks_from_bags(a["bag_input_filename"], a.count("bag_topic") ? a["bag_topic"] : "velodyne_points",
+                                       atof(a["total_long_distance"].c_str()), atof(a["total_short_distance"].c_str()),
+                                       atof(a["overlap_distance"].c_str()), longs, shorts))
+                return -1;
         } else if (a.count("sweeps")) {
             // raw lidar sweeps (the bags' /velodyne_points): input_data's replay + segmentation and the
             // four LOAM nodes run on the device, the tracks come back as /slam_track would carry them

@@ -6,6 +6,7 @@
 #include <stdexcept>
 
 #include "gps_process.h"
+#include "rosbag_reader.h"
 #include "track_process.h"
 
 extern "C" int gpscal_host_pipeline(const char *gps_log, const double *long_xyzt, const int *long_off, int nlong,
@@ -136,5 +137,26 @@ extern "C" int gpscal_host_pipeline_sweeps(const char *gps_log, int nbag, const 
         fprintf(stderr, "gpscal_host_pipeline_sweeps: %s\n", e.what());
         return 1;
     }
+    return 0;
+}
+
+// Reads one bag's PointCloud2 topic into caller buffers (tests / tools).  Returns 0, -2 when a
+// buffer is too small (nmsgs / npts then hold the required sizes), 1 on a malformed file.
+extern "C" int gpscal_host_read_bag(const char *path, const char *topic, float *xyz, int cap_pts, int *sweep_off,
+                                    double *stamps, int cap_msgs, int *nmsgs, int *npts)
+{
+    gpscal_host::CloudSeries S;
+    std::string err;
+    if (!gpscal_host::read_bag_clouds(path, topic, S, err)) {
+        fprintf(stderr, "gpscal_host_read_bag: %s\n", err.c_str());
+        return 1;
+    }
+    if (S.sweep_off.empty()) S.sweep_off.push_back(0);
+    *nmsgs = (int)S.stamps.size();
+    *npts = S.sweep_off.back();
+    if (*nmsgs > cap_msgs || *npts > cap_pts) return -2;
+    std::copy(S.xyz.begin(), S.xyz.end(), xyz);
+    std::copy(S.sweep_off.begin(), S.sweep_off.end(), sweep_off);
+    std::copy(S.stamps.begin(), S.stamps.end(), stamps);
     return 0;
 }

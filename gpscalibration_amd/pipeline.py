@@ -25,6 +25,8 @@ def load_host():
         _H.gpscal_host_pipeline_sweeps.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_double, C.c_double, C.c_double, C.c_char_p, C.c_int, C.c_char_p,
                                                    C.c_char_p, C.c_void_p, C.c_void_p]
+        _H.gpscal_host_read_bag.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_void_p]
     return _H
 
 
@@ -71,3 +73,22 @@ def run_sweeps(gps_log_path, bags, stamps, long_distance, short_distance, overla
     if rc != 0:
         raise RuntimeError("gpscal_host_pipeline_sweeps failed (%d)" % rc)
     return {"seconds": sec.tolist(), "counts": cnt.tolist()}
+
+
+def read_bag(path, topic="velodyne_points"):
+    """The PointCloud2 messages of one rosbag V2.0 file -> (list of [n,3] float32 sweeps, stamps)."""
+    H = load_host()
+    nm, npt = C.c_int(0), C.c_int(0)
+    dummy = np.zeros(1, dtype=np.float32)
+    rc = H.gpscal_host_read_bag(path.encode(), topic.encode(), dummy.ctypes.data, 0, dummy.ctypes.data,
+                                dummy.ctypes.data, 0, C.byref(nm), C.byref(npt))
+    if rc == 1:
+        raise RuntimeError("cannot read %s" % path)
+    xyz = np.zeros((max(npt.value, 1), 3), dtype=np.float32)
+    off = np.zeros(nm.value + 1, dtype=np.int32)
+    st = np.zeros(max(nm.value, 1), dtype=np.float64)
+    rc = H.gpscal_host_read_bag(path.encode(), topic.encode(), xyz.ctypes.data, len(xyz), off.ctypes.data,
+                                st.ctypes.data, nm.value, C.byref(nm), C.byref(npt))
+    if rc != 0:
+        raise RuntimeError("cannot read %s (%d)" % (path, rc))
+    return [xyz[off[k]:off[k + 1]].copy() for k in range(nm.value)], st[:nm.value].copy()

@@ -451,3 +451,80 @@ def write_sweep_file(path, bags, stamps):
                 sw = np.ascontiguousarray(sw, dtype=np.float32)
                 f.write(struct.pack("<di", float(t), len(sw)))
                 f.write(sw.tobytes())
+
+
+def write_rosbag(path, sweeps, stamps, topic="/velodyne_points", chunk_msgs=6, with_ring=True, compression="none"):
+    """Writes a rosbag V2.0 file holding one sensor_msgs/PointCloud2 message per sweep (Velodyne
+    layout: x, y, z, intensity float32 + ring uint16, point_step 32), with connection, chunk, index
+    and chunk-info records, as `rosbag record` lays them out.  compression: "none" or "bz2"."""
+    import bz2
+    import struct
+
+    def field(name, value):
+        b = name.encode() + b"=" + value
+        return struct.pack("<I", len(b)) + b
+
+    def record(header_fields, data):
+        h = b"".join(field(k, v) for k, v in header_fields)
+        return struct.pack("<I", len(h)) + h + struct.pack("<I", len(data)) + data
+
+    def ros_time(t):
+        secs = int(math.floor(t))
+        return struct.pack("<II", secs, int(round((t - secs) * 1e9)) % 1000000000)
+
+    def ros_str(s):
+        b = s.encode()
+        return struct.pack("<I", len(b)) + b
+
+    msg_def = "# synthetic\n"
+    conn_hdr = (field("topic", topic.encode()) + field("type", b"sensor_msgs/PointCloud2") +
+                field("md5sum", b"1158d486dd51d683ce2f1be655c3c181") + field("message_definition", msg_def.encode()))
+    conn_rec = record([("op", b"\x07"), ("conn", struct.pack("<I", 0)), ("topic", topic.encode())], conn_hdr)
+
+    def cloud_msg(seq, t, pts):
+        n = len(pts)
+        body = struct.pack("<I", seq) + ros_time(t) + ros_str("velodyne")
+        body += struct.pack("<II", 1, n)
+        fields = [("x", 0, 7), ("y", 4, 7), ("z", 8, 7), ("intensity", 16, 7)] + ([("ring", 20, 4)] if with_ring else [])
+        body += struct.pack("<I", len(fields))
+        for name, off, dt in fields:
+            body += ros_str(name) + struct.pack("<IBI", off, dt, 1)
+        step = 32
+        data = np.zeros((n, step), dtype=np.uint8)
+        data[:, 0:12] = np.ascontiguousarray(pts, dtype="<f4").view(np.uint8).reshape(n, 12)
+        body += struct.pack("<BII", 0, step, step * n) + struct.pack("<I", step * n) + data.tobytes() + struct.pack("<B", 1)
+        return body
+
+    chunks, infos = [], []
+    for c0 in range(0, len(sweeps), chunk_msgs):
+        body, index = conn_rec if c0 == 0 else b"", []
+        for k in range(c0, min(c0 + chunk_msgs, len(sweeps))):
+            index.append((stamps[k], len(body)))
+            body += record([("op", b"\x02"), ("conn", struct.pack("<I", 0)), ("time", ros_time(stamps[k]))],
+                           cloud_msg(k, stamps[k], sweeps[k]))
+        payload = bz2.compress(body) if compression == "bz2" else body
+        chunk = record([("op", b"\x05"), ("compression", compression.encode()), ("size", struct.pack("<I", len(body)))], payload)
+        idx = record([("op", b"\x04"), ("ver", struct.pack("<I", 1)), ("conn", struct.pack("<I", 0)),
+                      ("count", struct.pack("<I", len(index)))],
+                     b"".join(ros_time(t) + struct.pack("<I", o) for t, o in index))
+        chunks.append(chunk + idx)
+        infos.append((index[0][0], index[-1][0], len(index)))
+    with open(path, "wb") as f:
+        f.write(b"#ROSBAG V2.0\n")
+        pos = 13 + 4096
+        chunk_pos = []
+        for c in chunks:
+            chunk_pos.append(pos)
+            pos += len(c)
+        hdr = b"".join(field(k, v) for k, v in [("op", b"\x03"), ("index_pos", struct.pack("<Q", pos)),
+                                                ("conn_count", struct.pack("<I", 1)),
+                                                ("chunk_count", struct.pack("<I", len(chunks)))])
+        pad = 4096 - 4 - len(hdr) - 4
+        f.write(struct.pack("<I", len(hdr)) + hdr + struct.pack("<I", pad) + b" " * pad)
+        for c in chunks:
+            f.write(c)
+        f.write(conn_rec)
+        for cp, (t0, t1, cnt) in zip(chunk_pos, infos):
+            f.write(record([("op", b"\x06"), ("ver", struct.pack("<I", 1)), ("chunk_pos", struct.pack("<Q", cp)),
+                            ("start_time", ros_time(t0)), ("end_time", ros_time(t1)), ("count", struct.pack("<I", 1))],
+                           struct.pack("<II", 0, cnt)))

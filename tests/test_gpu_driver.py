@@ -115,6 +115,19 @@ def test_raw_sweeps_to_kml_matches_oracle(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert p.returncode == 0, p.stdout
     assert k2.read_text() == k0.read_text() and k3.read_text() == k1.read_text()
+    # ... and from rosbag files listed in a bag list, run.sh's own input (two bags: the segments span them)
+    b1, b2, lst = tmp_path / "part1.bag", tmp_path / "part2.bag", tmp_path / "bag_list.txt"
+    synth.write_rosbag(str(b1), bag[:80], st[:80])
+    synth.write_rosbag(str(b2), bag[80:], st[80:], compression="bz2")
+    lst.write_text("%s\n%s\n" % (b1, b2))
+    k4, k5 = tmp_path / "ori3.kml", tmp_path / "cal3.kml"
+    p = subprocess.run([RUN, "--gps_input_filename", str(log), "--bag_input_filename", str(lst),
+                        "--gps_original_filename", str(k4), "--gps_improved_filename", str(k5),
+                        "--total_long_distance", str(L), "--total_short_distance", str(S), "--overlap_distance", str(OV),
+                        "--kml_config", "/nonexistent"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout
+    assert k4.read_text() == k0.read_text() and k5.read_text() == k1.read_text()
     # and the calibrated track is a sensible answer: within a few metres of the true path's GPS fixes
     lat, lon, _ = O.parse_gprmc(gprmc, st[0], st[-1])
     assert abs(c1[:, 1].mean() - np.mean(lat)) < 1e-3 and abs(c1[:, 0].mean() - np.mean(lon)) < 1e-3
