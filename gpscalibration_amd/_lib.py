@@ -18,6 +18,7 @@ EXPORTS = [
     "gpscal_icp_iterate", "gpscal_icp_run",
     "gpscal_loam_odometry_batched", "gpscal_loam_mapping_batched", "gpscal_loam_transform",
     "gpscal_scan_registration_batched", "gpscal_voxel_grid_batched", "gpscal_loam_run_batched", "gpscal_input_data_run",
+    "gpscal_gps_to_gcj", "gpscal_gcj_to_bd", "gpscal_bd_to_gcj",
     "gpscal_comm_unique_id", "gpscal_comm_init", "gpscal_allgather_chains", "gpscal_comm_destroy",
 ]
 
@@ -98,6 +99,8 @@ def load():
     L.gpscal_loam_run_batched.argtypes = [vp, i, fp, ip, ip, dp, fp, fp, fp, dp, ip, i, i]
     L.gpscal_input_data_run.argtypes = [vp, i, fp, ip, ip, dp, C.c_double, C.c_double, C.c_double, i, ip, ip, ip, ip, ip,
                                          dp, i, ip, i, i]
+    for name in ("gpscal_gps_to_gcj", "gpscal_gcj_to_bd", "gpscal_bd_to_gcj"):
+        getattr(L, name).argtypes = [vp, dp, i, dp]
     L.gpscal_loam_transform.argtypes = [vp, fp, fp, i, fp, i]
     L.gpscal_comm_unique_id.argtypes = [vp]
     L.gpscal_comm_init.argtypes = [vp, vp, i, i]

@@ -314,6 +314,13 @@ class Context:
         return [{"flag": int(flag[k]), "bag": int(bag[k]), "first": int(first[k]), "last": int(last[k]),
                  "track": rows[toff[k]:toff[k + 1]].copy()} for k in range(int(nt[0]))]
 
+    def mars(self, lonlat, which):
+        """GCJ-02 / BD-09 conversions of [n,2] {lon, lat}: which = "gps_to_gcj" | "gcj_to_bd" | "bd_to_gcj"."""
+        p = _f64(lonlat)
+        out = np.empty_like(p)
+        self._ck(getattr(self._L, "gpscal_" + which)(self._h, _ptr(p), len(p), _ptr(out)), which)
+        return out
+
     def loam_transform(self, transform6, pts_xyzi, to_end=False):
         t = np.ascontiguousarray(transform6, dtype=np.float32)
         p = np.ascontiguousarray(pts_xyzi, dtype=np.float32)

@@ -382,3 +382,103 @@ extern "C" int gpscal_gps_to_enu_batched(gpscal_ctx *ctx, int method, int band_t
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GPSCAL_OK;
 }
+
+// ------------------------------------------------------------ GCJ-02 / BD-09
+// GPSPro::GPSToGCJ / GCJToBD / BDToGCJ (gps_process.cc:526-595) with transform2Mars, bd_encrypt,
+// bd_decrypt (:1127-1207): the "Mars" offset polynomial of the Chinese map datums on {longitude,
+// latitude} pairs, float64, one lane per point.  PI is the reference's truncated 3.141592653589
+// (common.h:17), X_PI its 3.1415926535897932384626 * 3000 / 180 (common.h:27).
+namespace gpscal {
+
+constexpr double MARS_PI = 3.141592653589;
+constexpr double MARS_A = 6378245.0, MARS_B = 6356863.0188;
+constexpr double MARS_XPI = 3.1415926535897932384626 * 3000.0 / 180.0;
+
+__device__ __forceinline__ double mars_lat(double x, double y)
+{
+    double ret = -100.0 + 2.0 * x + 3.0 * y + 0.2 * y * y + 0.1 * x * y + 0.2 * sqrt(fabs(x));
+    ret += (20.0 * sin(6.0 * x * MARS_PI) + 20.0 * sin(2.0 * x * MARS_PI)) * 2.0 / 3.0;
+    ret += (20.0 * sin(y * MARS_PI) + 40.0 * sin(y / 3.0 * MARS_PI)) * 2.0 / 3.0;
+    ret += (160.0 * sin(y / 12.0 * MARS_PI) + 320 * sin(y * MARS_PI / 30.0)) * 2.0 / 3.0;
+    return ret;
+}
+
+__device__ __forceinline__ double mars_lon(double x, double y)
+{
+    double ret = 300.0 + x + 2.0 * y + 0.1 * x * x + 0.1 * x * y + 0.1 * sqrt(fabs(x));
+    ret += (20.0 * sin(6.0 * x * MARS_PI) + 20.0 * sin(2.0 * x * MARS_PI)) * 2.0 / 3.0;
+    ret += (20.0 * sin(x * MARS_PI) + 40.0 * sin(x / 3.0 * MARS_PI)) * 2.0 / 3.0;
+    ret += (150.0 * sin(x / 12.0 * MARS_PI) + 300.0 * sin(x / 30.0 * MARS_PI)) * 2.0 / 3.0;
+    return ret;
+}
+
+// mode 0: WGS-84 -> GCJ-02, 1: GCJ-02 -> BD-09, 2: BD-09 -> GCJ-02
+__global__ void mars_kernel(int mode, const double *__restrict__ in, int n, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double lon = in[2 * i], lat = in[2 * i + 1];
+    double olon, olat;
+    if (mode == 0) {
+        if (lon < 72.004 || lon > 137.8347 || lat < 0.8293 || lat > 55.8271) {  // outOfChina, :1127-1138
+            olat = lat;
+            olon = lon;
+        } else {
+            const double ee = (MARS_A * MARS_A - MARS_B * MARS_B) / (MARS_A * MARS_A);  // common.h:29
+            double dLat = mars_lat(lon - 105.0, lat - 35.0), dLon = mars_lon(lon - 105.0, lat - 35.0);
+            const double radLat = lat / 180.0 * MARS_PI;
+            double magic = sin(radLat);
+            magic = 1 - ee * magic * magic;
+            const double sqrtMagic = sqrt(magic);
+            dLat = (dLat * 180.0) / ((MARS_A * (1 - ee)) / (magic * sqrtMagic) * MARS_PI);
+            dLon = (dLon * 180.0) / (MARS_A / sqrtMagic * cos(radLat) * MARS_PI);
+            olat = lat + dLat;
+            olon = lon + dLon;
+        }
+    } else if (mode == 1) {
+        const double x = lon, y = lat;
+        const double z = sqrt(x * x + y * y) + 0.00002 * sin(y * MARS_XPI);
+        const double theta = atan2(y, x) + 0.000003 * cos(x * MARS_XPI);
+        olon = z * cos(theta) + 0.0065;
+        olat = z * sin(theta) + 0.006;
+    } else {
+        const double x = lon - 0.0065, y = lat - 0.006;
+        const double z = sqrt(x * x + y * y) - 0.00002 * sin(y * MARS_XPI);
+        const double theta = atan2(y, x) - 0.000003 * cos(x * MARS_XPI);
+        olon = z * cos(theta);
+        olat = z * sin(theta);
+    }
+    out[2 * i] = olon;
+    out[2 * i + 1] = olat;
+}
+
+static int run_mars(gpscal_ctx *ctx, int mode, const double *lonlat, int n, double *out, const char *who)
+{
+    if (!ctx || !lonlat || !out || n < 1) return fail(ctx, GPSCAL_EINVAL, who);
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    InArg<double> a;
+    OutArg<double> o;
+    GPSCAL_HIP(ctx, a.bind(ctx, lonlat, (size_t)n * 2));
+    GPSCAL_HIP(ctx, o.bind(ctx, out, (size_t)n * 2));
+    hipLaunchKernelGGL(mars_kernel, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, mode, a.dev, n, o.dev);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    bool sync = true;
+    GPSCAL_HIP(ctx, o.commit(ctx, &sync));
+    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}
+
+}  // namespace gpscal
+
+extern "C" int gpscal_gps_to_gcj(gpscal_ctx *ctx, const double *lonlat, int n, double *gcj_lonlat)
+{
+    return gpscal::run_mars(ctx, 0, lonlat, n, gcj_lonlat, "gpscal_gps_to_gcj: bad argument");
+}
+extern "C" int gpscal_gcj_to_bd(gpscal_ctx *ctx, const double *gcj_lonlat, int n, double *bd_lonlat)
+{
+    return gpscal::run_mars(ctx, 1, gcj_lonlat, n, bd_lonlat, "gpscal_gcj_to_bd: bad argument");
+}
+extern "C" int gpscal_bd_to_gcj(gpscal_ctx *ctx, const double *bd_lonlat, int n, double *gcj_lonlat)
+{
+    return gpscal::run_mars(ctx, 2, bd_lonlat, n, gcj_lonlat, "gpscal_bd_to_gcj: bad argument");
+}

@@ -70,6 +70,58 @@ double ddmm_to_deg(const char *tok)
     const int d = (int)(v / 100);  // truncation as in gps_process.cc:191,205
     return d + (v - d * 100) / 60.0;
 }
+
+enum { SENTENCE_NONE = 0, SENTENCE_RMC = 1, SENTENCE_GGA = 2, SENTENCE_GLL = 3 };
+
+// gps_process.cc:128-152: the second field of the first line names the sentence of the whole log
+int sniff_sentence(const Fields &F)
+{
+    if (F.f.size() < 2) return SENTENCE_NONE;
+    if (strcmp(F.f[1], "$GPRMC") == 0) return SENTENCE_RMC;
+    if (strcmp(F.f[1], "$GPGGA") == 0) return SENTENCE_GGA;
+    if (strcmp(F.f[1], "$GPGLL") == 0) return SENTENCE_GLL;
+    return SENTENCE_NONE;
+}
+
+// One line of the log (getGPRMCFormat gps_process.cc:161-229, getGPGGAFormat :231-299,
+// getGPGLLFormat :300-372), column walk with the reference's early exits.  Returns false when the
+// fix must not be kept whatever its stamp (GPGGA without coordinates, :293).
+bool parse_fix(int kind, const Fields &F, double &stamp, double &la, double &lo)
+{
+    stamp = 0;
+    la = 90;  // (90,180) marks "no fix" (gps_process.cc:169)
+    lo = 180;
+    const size_t n = F.f.size();
+    if (n >= 1) stamp = atof(F.f[0]);
+    if (kind == SENTENCE_RMC) {
+        if (n >= 4 && strcmp(F.f[3], "V") == 0) return true;  // :176-179
+        if (n >= 5) la = ddmm_to_deg(F.f[4]);
+        if (n >= 6 && strcmp(F.f[5], "S") == 0) la = 0 - la;
+        if (n >= 7) lo = ddmm_to_deg(F.f[6]);
+        if (n >= 8 && strcmp(F.f[7], "W") == 0) lo = 0 - lo;
+        return true;
+    }
+    if (kind == SENTENCE_GGA) {
+        if (n >= 4) la = ddmm_to_deg(F.f[3]);
+        if (n >= 5) {
+            if (strcmp(F.f[4], "N") != 0 && strcmp(F.f[4], "S") != 0) return !(la == 90 || lo == 180);  // :246-249
+            if (strcmp(F.f[4], "S") == 0) la = 0 - la;
+        }
+        if (n >= 6) lo = ddmm_to_deg(F.f[5]);
+        if (n >= 7) {
+            if (strcmp(F.f[6], "W") != 0 && strcmp(F.f[6], "E") != 0) return !(la == 90 || lo == 180);  // :250-253
+            if (strcmp(F.f[6], "W") == 0) lo = 0 - lo;
+        }
+        return !(la == 90 || lo == 180);  // :293
+    }
+    // GPGLL: a status V in column 8 ends the walk after every coordinate column (:315-318), and the
+    // fix is kept without a sentinel test (:364)
+    if (n >= 3) la = ddmm_to_deg(F.f[2]);
+    if (n >= 4 && strcmp(F.f[3], "S") == 0) la = 0 - la;
+    if (n >= 5) lo = ddmm_to_deg(F.f[4]);
+    if (n >= 6 && strcmp(F.f[5], "W") == 0) lo = 0 - lo;
+    return true;
+}
 }  // namespace
 
 int GPSPro::parseGPRMC(const std::string &path, double startTime, double endTime, std::vector<double> &lat,
@@ -81,28 +133,20 @@ int GPSPro::parseGPRMC(const std::string &path, double startTime, double endTime
         return 1;
     }
     std::string line;
-    bool first = true;
+    int kind = -1;
     while (std::getline(in, line)) {
         if (line.size() >= IMSDLEN) break;  // the reference's 512-byte getline would fail here
         Fields F(line);
-        if (first) {
-            first = false;
-            // format sniffing on the 2nd field of the first line (gps_process.cc:129-154)
-            if (F.f.size() < 2 || strcmp(F.f[1], "$GPRMC") != 0) {
+        if (kind < 0) {
+            kind = sniff_sentence(F);  // gps_process.cc:129-154
+            if (kind == SENTENCE_NONE) {
                 printf("[WARNING] The current version does not support the current GPS format\n");
                 return 0;
             }
         }
-        double stamp = 0, la = 90, lo = 180;  // (90,180) marks "no fix" (gps_process.cc:169)
-        if (!F.f.empty()) stamp = atof(F.f[0]);
-        const bool novalid = F.f.size() >= 4 && strcmp(F.f[3], "V") == 0;
-        if (!novalid) {
-            if (F.f.size() >= 5) la = ddmm_to_deg(F.f[4]);
-            if (F.f.size() >= 6 && strcmp(F.f[5], "S") == 0) la = 0 - la;
-            if (F.f.size() >= 7) lo = ddmm_to_deg(F.f[6]);
-            if (F.f.size() >= 8 && strcmp(F.f[7], "W") == 0) lo = 0 - lo;
-        }
-        if ((long)stamp >= (long)(startTime - 1) && (long)stamp <= (long)(endTime + 1)) {
+        double stamp, la, lo;
+        const bool keep = parse_fix(kind, F, stamp, la, lo);
+        if (keep && (long)stamp >= (long)(startTime - 1) && (long)stamp <= (long)(endTime + 1)) {
             lat.push_back(la);
             lon.push_back(lo);
             t.push_back(stamp);
@@ -187,29 +231,24 @@ bool GPSPro::loadLog()
         return false;
     }
     std::string line;
-    bool first = true;
+    int kind = -1;
+    logKeep.clear();
     while (std::getline(in, line)) {
         if (line.size() >= IMSDLEN) break;
         Fields F(line);
-        if (first) {
-            first = false;
-            if (F.f.size() < 2 || strcmp(F.f[1], "$GPRMC") != 0) {
+        if (kind < 0) {
+            kind = sniff_sentence(F);
+            if (kind == SENTENCE_NONE) {
                 printf("[WARNING] The current version does not support the current GPS format\n");
                 break;
             }
         }
-        double stamp = 0, la = 90, lo = 180;
-        if (!F.f.empty()) stamp = atof(F.f[0]);
-        const bool novalid = F.f.size() >= 4 && strcmp(F.f[3], "V") == 0;
-        if (!novalid) {
-            if (F.f.size() >= 5) la = ddmm_to_deg(F.f[4]);
-            if (F.f.size() >= 6 && strcmp(F.f[5], "S") == 0) la = 0 - la;
-            if (F.f.size() >= 7) lo = ddmm_to_deg(F.f[6]);
-            if (F.f.size() >= 8 && strcmp(F.f[7], "W") == 0) lo = 0 - lo;
-        }
+        double stamp, la, lo;
+        const bool keep = parse_fix(kind, F, stamp, la, lo);
         logLat.push_back(la);
         logLon.push_back(lo);
         logT.push_back(stamp);
+        logKeep.push_back(keep ? 1 : 0);
     }
     logLoaded = true;
     return true;
@@ -221,7 +260,7 @@ void GPSPro::window(double startTime, double endTime, std::vector<double> &lat, 
     // the scan of getGPRMCFormat (gps_process.cc:167-227) over the cached lines
     for (size_t i = 0; i < logT.size(); ++i) {
         const double stamp = logT[i];
-        if ((long)stamp >= (long)(startTime - 1) && (long)stamp <= (long)(endTime + 1)) {
+        if (logKeep[i] && (long)stamp >= (long)(startTime - 1) && (long)stamp <= (long)(endTime + 1)) {
             lat.push_back(logLat[i]);
             lon.push_back(logLon[i]);
             t.push_back(stamp);
@@ -420,4 +459,63 @@ int GPSPro::createKML(std::string name, std::vector<std::pair<double, double> > 
     fwrite(o.data(), 1, o.size(), fp);
     fclose(fp);
     return 0;
+}
+
+// ------------------------------------------------------------- GCJ-02 / BD-09 / JSON
+
+namespace {
+int mars(const char *who, int (*fn)(gpscal_ctx *, const double *, int, double *),
+         const std::vector<std::pair<double, double> > &in, std::vector<std::pair<double, double> > &out)
+{
+    if (in.empty()) {
+        printf("%s data NULL\n", who);  // gps_process.cc:528-532
+        return -1;
+    }
+    static_assert(sizeof(std::pair<double, double>) == 16, "pairs are passed as packed doubles");
+    std::vector<std::pair<double, double> > tmp(in.size());
+    check(fn(default_ctx(), &in[0].first, (int)in.size(), &tmp[0].first), who);
+    out.insert(out.end(), tmp.begin(), tmp.end());  // the reference push_backs onto the caller's vector
+    return 0;
+}
+}  // namespace
+
+int GPSPro::GPSToGCJ(std::vector<std::pair<double, double> > v, std::vector<std::pair<double, double> > &o)
+{
+    return mars("GPS", gpscal_gps_to_gcj, v, o);
+}
+int GPSPro::GCJToBD(std::vector<std::pair<double, double> > v, std::vector<std::pair<double, double> > &o)
+{
+    return mars("GCJ02", gpscal_gcj_to_bd, v, o);
+}
+int GPSPro::BDToGCJ(std::vector<std::pair<double, double> > v, std::vector<std::pair<double, double> > &o)
+{
+    return mars("BD09", gpscal_bd_to_gcj, v, o);
+}
+
+void GPSPro::createJSON(std::string fileName, std::vector<std::pair<double, double> > GPSValue, int flag,
+                        std::vector<std::pair<int, std::string> > segmentColor)
+{
+    FILE *fp = fopen(fileName.c_str(), "w");
+    if (!fp) {
+        printf("ERROR: open %s error.\n", fileName.c_str());
+        throw std::runtime_error("createJSON: cannot open " + fileName);  // the reference exit(0)s
+    }
+    // ofstream << double with precision(15) is printf("%.15g")
+    size_t index = 0;
+    if (flag == 0) {
+        fputs("[{\"line\":[", fp);
+        for (; index < GPSValue.size(); ++index) fprintf(fp, "[%.15g,%.15g],", GPSValue[index].first, GPSValue[index].second);
+        fputs("],\"color\":\"FF00FF\"}]", fp);
+    } else {
+        fputs("[", fp);
+        for (size_t c = 0; c < segmentColor.size(); ++c) {
+            fputs("{\"line\":[", fp);
+            for (; (long)index <= (long)segmentColor[c].first && index < GPSValue.size(); ++index)
+                fprintf(fp, "[%.15g,%.15g],", GPSValue[index].first, GPSValue[index].second);
+            fprintf(fp, "],\"color\":\"%s\"},", segmentColor[c].second.c_str());
+        }
+        fputs("]", fp);
+    }
+    fclose(fp);
+    printf("finished map\n");
 }

@@ -33,6 +33,14 @@ public:
     int createKML(std::string KMLFileName, std::vector<std::pair<double, double> > WGSBL, std::vector<double> altitude,
                   int flag, std::vector<std::pair<int, std::string> > segmentColor);
 
+    // WGS-84 -> GCJ-02 -> BD-09 and back (gps_process.cc:526-595), pairs {longitude, latitude}
+    int GPSToGCJ(std::vector<std::pair<double, double> > vecGpsCoor, std::vector<std::pair<double, double> > &vecGCJ);
+    int GCJToBD(std::vector<std::pair<double, double> > vecGCJCoor, std::vector<std::pair<double, double> > &vecBD);
+    int BDToGCJ(std::vector<std::pair<double, double> > vecBDCoor, std::vector<std::pair<double, double> > &vecGCJ);
+    // map-API JSON writer (gps_process.cc:1210-1250), flag as createKML
+    void createJSON(std::string fileName, std::vector<std::pair<double, double> > GPSValue, int flag,
+                    std::vector<std::pair<int, std::string> > segmentColor);
+
     // host-side pieces, exposed for tests
     static int parseGPRMC(const std::string &path, double startTime, double endTime, std::vector<double> &lat,
                           std::vector<double> &lon, std::vector<double> &t);
@@ -48,6 +56,7 @@ private:
     // parsed log (all lines, sentinel for 'V'), in file order; stamp 0 for blank lines
     bool logLoaded = false;
     std::vector<double> logLat, logLon, logT;
+    std::vector<char> logKeep;  // 0: a $GPGGA line without coordinates, never kept (gps_process.cc:293)
     bool loadLog();
     void window(double startTime, double endTime, std::vector<double> &lat, std::vector<double> &lon,
                 std::vector<double> &t) const;

@@ -292,8 +292,28 @@ int main(int argc, char **argv)
         gps.ENUToGPS(sp.result(), impWGSBL, impAlt, impCol);
         printf("oriWGSBL.size() = %zu\n", oriWGSBL.size());
         const int rc = atoi(a["result_control"].c_str());
-        if (rc == 2 || rc == 3 || rc == 4)
-            fprintf(stderr, "result_control %d (Baidu/Gaode/ROS message) is not built yet: writing KML\n", rc);
+        if (rc == 2) {  // BAIDU_MAP_FILE, short_distance_track_process.cpp:271-282
+            std::vector<std::pair<double, double> > GCJ02, BD09;
+            gps.GPSToGCJ(oriWGSBL, GCJ02);
+            gps.GCJToBD(GCJ02, BD09);
+            gps.createJSON(a["gps_original_filename"], BD09, 0, oriCol);
+            GCJ02.clear();
+            BD09.clear();
+            gps.GPSToGCJ(impWGSBL, GCJ02);
+            gps.GCJToBD(GCJ02, BD09);
+            gps.createJSON(a["gps_improved_filename"], BD09, 1, impCol);
+            return 0;
+        }
+        if (rc == 3) {  // GAODE_MAP_FILE, short_distance_track_process.cpp:283-291
+            std::vector<std::pair<double, double> > GCJ02;
+            gps.GPSToGCJ(oriWGSBL, GCJ02);
+            gps.createJSON(a["gps_original_filename"], GCJ02, 0, oriCol);
+            GCJ02.clear();
+            gps.GPSToGCJ(impWGSBL, GCJ02);
+            gps.createJSON(a["gps_improved_filename"], GCJ02, 1, impCol);
+            return 0;
+        }
+        if (rc == 4) fprintf(stderr, "result_control 4 publishes a ROS message (/imorpheus_gps); without ROS: writing KML\n");
         printf("====================  Create original GPS KML  ====================\n");
         gps.createKML(a["gps_original_filename"], oriWGSBL, oriAlt, 0, oriCol);
         printf("==================== Create calibrated GPS KML ====================\n");

@@ -254,6 +254,14 @@ int gpscal_loam_mapping_batched(gpscal_ctx *ctx, int nsweeps,
 int gpscal_loam_transform(gpscal_ctx *ctx, const float *transform6,
                           const float *pts_xyzi, int n, float *out_xyzi, int to_end);
 
+/* GPSPro::GPSToGCJ / GCJToBD / BDToGCJ (GP:526-595; transform2Mars, bd_encrypt, bd_decrypt
+ * GP:1127-1207): WGS-84 -> GCJ-02 (Gaode), GCJ-02 <-> BD-09 (Baidu) on n {longitude, latitude}
+ * pairs as gpscal_enu_to_wgs emits them; the map outputs of result_control 2 / 3
+ * (short_distance_track_process.cpp:271-291). */
+int gpscal_gps_to_gcj(gpscal_ctx *ctx, const double *lonlat, int n, double *gcj_lonlat);
+int gpscal_gcj_to_bd(gpscal_ctx *ctx, const double *gcj_lonlat, int n, double *bd_lonlat);
+int gpscal_bd_to_gcj(gpscal_ctx *ctx, const double *bd_lonlat, int n, double *gcj_lonlat);
+
 /* ------------------------------------------------ scanRegistration, VoxelGrid */
 /* Replaces scanRegistration's laserCloudHandler (SR:238-674, IMU inactive) for nsweeps raw
  * sweeps in one launch: NaN removal, start / end orientation (SR:262-281), ring id from the

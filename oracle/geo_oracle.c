@@ -101,6 +101,183 @@ int orc_parse_gprmc(const char *text, size_t len, double t0, double t1,
     return count;
 }
 
+
+/* GP:231-299 ($GPGGA) and GP:300-372 ($GPGLL): same line loop, other columns.  kind 1 = GPGGA,
+ * 2 = GPGLL.  GPGLL pushes fixes with status V as they are (no sentinel test, GP:364). */
+static int parse_gga_gll(int kind, const char *text, size_t len, double t0, double t1, double *lat, double *lon,
+                         double *t, int cap)
+{
+    int count = 0;
+    size_t pos = 0;
+    char buf[LINE_CAP];
+    while (pos < len) {
+        size_t e = pos;
+        while (e < len && text[e] != '\n') ++e;
+        size_t l = e - pos;
+        if (l > LINE_CAP - 1) break;
+        memcpy(buf, text + pos, l);
+        buf[l] = '\0';
+        pos = e < len ? e + 1 : e;
+        int column = 0;
+        double latitude = 90, longitude = 180, stamp = 0;
+        char *cur = buf;
+        const int c_lat = kind == 1 ? 4 : 3;
+        for (char *tok = next_tok(&cur); tok; tok = next_tok(&cur)) {
+            ++column;
+            if (kind == 1) { /* GP:246-253 */
+                if (column == 5 && strcmp("N", tok) != 0 && strcmp("S", tok) != 0) break;
+                if (column == 7 && strcmp("W", tok) != 0 && strcmp("E", tok) != 0) break;
+            } else if (column == 8 && strcmp("V", tok) == 0) { /* GP:315-318 */
+                break;
+            }
+            if (column == 1) stamp = atof(tok);
+            else if (column == c_lat) {
+                int d = (int)(atof(tok) / 100);
+                latitude = d + (atof(tok) - d * 100) / 60.0;
+            } else if (column == c_lat + 1) {
+                if (strcmp("S", tok) == 0) latitude = 0 - latitude;
+            } else if (column == c_lat + 2) {
+                int d = (int)(atof(tok) / 100);
+                longitude = d + (atof(tok) - d * 100) / 60.0;
+            } else if (column == c_lat + 3) {
+                if (strcmp("W", tok) == 0) longitude = 0 - longitude;
+            }
+        }
+        int keep = (long)stamp >= (long)(t0 - 1) && (long)stamp <= (long)(t1 + 1);
+        if (kind == 1) keep = keep && 90 != latitude && 180 != longitude; /* GP:293 */
+        if (keep) {
+            if (count >= cap) return -2;
+            lat[count] = latitude;
+            lon[count] = longitude;
+            t[count] = stamp;
+            ++count;
+        }
+        if (!(stamp < t1 + 1)) break;
+    }
+    return count;
+}
+
+int orc_parse_gps_log(const char *text, size_t len, double t0, double t1, double *lat, double *lon, double *t,
+                      int cap)
+{
+    /* GP:128-152: the second comma-separated token of the FIRST line names the sentence */
+    char buf[LINE_CAP];
+    size_t e = 0;
+    while (e < len && text[e] != '\n') ++e;
+    if (e > LINE_CAP - 1) return -1;
+    memcpy(buf, text, e);
+    buf[e] = '\0';
+    char *cur = buf;
+    char *tok = next_tok(&cur);
+    tok = tok ? next_tok(&cur) : NULL;
+    if (!tok) return -1; /* the reference dereferences NULL here */
+    if (strcmp("$GPRMC", tok) == 0) return orc_parse_gprmc(text, len, t0, t1, lat, lon, t, cap);
+    if (strcmp("$GPGGA", tok) == 0) return parse_gga_gll(1, text, len, t0, t1, lat, lon, t, cap);
+    if (strcmp("$GPGLL", tok) == 0) return parse_gga_gll(2, text, len, t0, t1, lat, lon, t, cap);
+    return 0; /* "[WARNING] The current version does not support the current GPS format" */
+}
+
+/* ------------------------------------------------ GCJ-02 / BD-09 (GP:1127-1207) */
+#define ORC_PI 3.141592653589 /* common.h:17 */
+#define ORC_LONG_AXIS 6378245.0
+#define ORC_SHORT_AXIS 6356863.0188
+#define ORC_X_PI (3.1415926535897932384626 * 3000.0 / 180.0)
+
+static double mars_lat(double x, double y)
+{
+    double ret = -100.0 + 2.0 * x + 3.0 * y + 0.2 * y * y + 0.1 * x * y + 0.2 * sqrt(fabs(x));
+    ret += (20.0 * sin(6.0 * x * ORC_PI) + 20.0 * sin(2.0 * x * ORC_PI)) * 2.0 / 3.0;
+    ret += (20.0 * sin(y * ORC_PI) + 40.0 * sin(y / 3.0 * ORC_PI)) * 2.0 / 3.0;
+    ret += (160.0 * sin(y / 12.0 * ORC_PI) + 320 * sin(y * ORC_PI / 30.0)) * 2.0 / 3.0;
+    return ret;
+}
+
+static double mars_lon(double x, double y)
+{
+    double ret = 300.0 + x + 2.0 * y + 0.1 * x * x + 0.1 * x * y + 0.1 * sqrt(fabs(x));
+    ret += (20.0 * sin(6.0 * x * ORC_PI) + 20.0 * sin(2.0 * x * ORC_PI)) * 2.0 / 3.0;
+    ret += (20.0 * sin(x * ORC_PI) + 40.0 * sin(x / 3.0 * ORC_PI)) * 2.0 / 3.0;
+    ret += (150.0 * sin(x / 12.0 * ORC_PI) + 300.0 * sin(x / 30.0 * ORC_PI)) * 2.0 / 3.0;
+    return ret;
+}
+
+/* GPSToGCJ (GP:526-545) on {longitude, latitude} pairs, as ENUToGPS emits them */
+void orc_gps_to_gcj(const double *lonlat, int n, double *out)
+{
+    const double ee = (ORC_LONG_AXIS * ORC_LONG_AXIS - ORC_SHORT_AXIS * ORC_SHORT_AXIS) / (ORC_LONG_AXIS * ORC_LONG_AXIS);
+    for (int i = 0; i < n; ++i) {
+        const double lon = lonlat[2 * i], lat = lonlat[2 * i + 1];
+        double glat, glon;
+        if (lon < 72.004 || lon > 137.8347 || lat < 0.8293 || lat > 55.8271) { /* outOfChina, GP:1127-1138 */
+            glat = lat;
+            glon = lon;
+        } else {
+            double dLat = mars_lat(lon - 105.0, lat - 35.0), dLon = mars_lon(lon - 105.0, lat - 35.0);
+            double radLat = lat / 180.0 * ORC_PI;
+            double magic = sin(radLat);
+            magic = 1 - ee * magic * magic;
+            double sqrtMagic = sqrt(magic);
+            dLat = (dLat * 180.0) / ((ORC_LONG_AXIS * (1 - ee)) / (magic * sqrtMagic) * ORC_PI);
+            dLon = (dLon * 180.0) / (ORC_LONG_AXIS / sqrtMagic * cos(radLat) * ORC_PI);
+            glat = lat + dLat;
+            glon = lon + dLon;
+        }
+        out[2 * i] = glon;
+        out[2 * i + 1] = glat;
+    }
+}
+
+/* GCJToBD / BDToGCJ (GP:551-595, 1183-1207) */
+void orc_gcj_to_bd(const double *lonlat, int n, double *out)
+{
+    for (int i = 0; i < n; ++i) {
+        double x = lonlat[2 * i], y = lonlat[2 * i + 1];
+        double z = sqrt(x * x + y * y) + 0.00002 * sin(y * ORC_X_PI);
+        double theta = atan2(y, x) + 0.000003 * cos(x * ORC_X_PI);
+        out[2 * i] = z * cos(theta) + 0.0065;
+        out[2 * i + 1] = z * sin(theta) + 0.006;
+    }
+}
+
+void orc_bd_to_gcj(const double *lonlat, int n, double *out)
+{
+    for (int i = 0; i < n; ++i) {
+        double x = lonlat[2 * i] - 0.0065, y = lonlat[2 * i + 1] - 0.006;
+        double z = sqrt(x * x + y * y) - 0.00002 * sin(y * ORC_X_PI);
+        double theta = atan2(y, x) - 0.000003 * cos(x * ORC_X_PI);
+        out[2 * i] = z * cos(theta);
+        out[2 * i + 1] = z * sin(theta);
+    }
+}
+
+/* createJSON (GP:1210-1250): ofstream with precision(15) = "%.15g" */
+long orc_json(char *buf, size_t cap, const double *lonlat, int n, int flag, const int *seg_end, const uint32_t *rgb,
+              int nseg)
+{
+    size_t at = 0;
+#define JPUT(...)                                                              \
+    do {                                                                       \
+        int k_ = snprintf(at < cap ? buf + at : NULL, at < cap ? cap - at : 0, __VA_ARGS__); \
+        at += (size_t)k_;                                                      \
+    } while (0)
+    int index = 0;
+    if (flag == 0) {
+        JPUT("[{\"line\":[");
+        for (; index < n; ++index) JPUT("[%.15g,%.15g],", lonlat[2 * index], lonlat[2 * index + 1]);
+        JPUT("],\"color\":\"FF00FF\"}]");
+    } else {
+        JPUT("[");
+        for (int c = 0; c < nseg; ++c) {
+            JPUT("{\"line\":[");
+            for (; index <= seg_end[c]; ++index) JPUT("[%.15g,%.15g],", lonlat[2 * index], lonlat[2 * index + 1]);
+            JPUT("],\"color\":\"%06X\"},", (unsigned)rgb[c]);
+        }
+        JPUT("]");
+    }
+#undef JPUT
+    return (long)at;
+}
+
 /* -------------------------------------------------------------- gap fill */
 
 int orc_gap_fill(double *lat, double *lon, const double *t, int n)

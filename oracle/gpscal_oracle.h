@@ -77,6 +77,18 @@ int orc_long_segment(const double *slam_xyzt, const double *enu_xyzt, int n,
  * for status 'V' (GP:169,176-179). */
 int orc_parse_gprmc(const char *text, size_t len, double t0, double t1,
                     double *lat, double *lon, double *t, int cap);
+/* GP:113-159: the sentence named by the first line's second field selects the parser -- $GPRMC
+ * (above), $GPGGA (GP:231-299), $GPGLL (GP:300-372).  Returns fixes written, 0 for an unsupported
+ * sentence, <0 on error. */
+int orc_parse_gps_log(const char *text, size_t len, double t0, double t1, double *lat, double *lon, double *t,
+                      int cap);
+/* GP:526-595, 1127-1207 on n {longitude, latitude} pairs. */
+void orc_gps_to_gcj(const double *lonlat, int n, double *out);
+void orc_gcj_to_bd(const double *lonlat, int n, double *out);
+void orc_bd_to_gcj(const double *lonlat, int n, double *out);
+/* createJSON, GP:1210-1250 (returns bytes needed, like snprintf). */
+long orc_json(char *buf, size_t cap, const double *lonlat, int n, int flag, const int *seg_end, const uint32_t *rgb,
+              int nseg);
 /* GP:389-473.  In-place dropout fill; returns the reference's return value. */
 int orc_gap_fill(double *lat, double *lon, const double *t, int n);
 /* GP:851-908 (method 0, "UTM") / GP:953-1007 (method 1, "Gaussion").

@@ -363,3 +363,34 @@ def input_data_pass(sweeps, stamps, slam_distance, overlap):
                                    _p(rows, c_dp), cap_r)
     assert nt >= 0
     return [{"first": int(first[k]), "last": int(last[k]), "track": rows[toff[k]:toff[k + 1]].copy()} for k in range(nt)]
+
+
+def parse_gps_log(text, t0, t1):
+    """getGPS's dispatch on the sentence of the first line (GPRMC / GPGGA / GPGLL)."""
+    if isinstance(text, str):
+        text = text.encode()
+    cap = text.count(b"\n") + 2
+    lat, lon, t = np.empty(cap), np.empty(cap), np.empty(cap)
+    n = lib().orc_parse_gps_log(text, C.c_size_t(len(text)), C.c_double(t0), C.c_double(t1),
+                                _p(lat, c_dp), _p(lon, c_dp), _p(t, c_dp), cap)
+    assert n >= 0
+    return lat[:n].copy(), lon[:n].copy(), t[:n].copy()
+
+
+def mars(lonlat, which):
+    ll = f64(lonlat)
+    out = np.empty_like(ll)
+    getattr(lib(), "orc_" + which)(_p(ll, c_dp), len(ll), _p(out, c_dp))
+    return out
+
+
+def json_map(lonlat, flag, seg_end=None, rgb=None):
+    ll = f64(lonlat)
+    nseg = 0 if seg_end is None else len(seg_end)
+    se = None if seg_end is None else np.ascontiguousarray(seg_end, dtype=np.int32)
+    cc = None if rgb is None else np.ascontiguousarray(rgb, dtype=np.uint32)
+    lib().orc_json.restype = C.c_long
+    need = lib().orc_json(None, C.c_size_t(0), _p(ll, c_dp), len(ll), flag, _p(se, c_ip), _p(cc, c_up), nseg)
+    buf = C.create_string_buffer(need + 1)
+    lib().orc_json(buf, C.c_size_t(need + 1), _p(ll, c_dp), len(ll), flag, _p(se, c_ip), _p(cc, c_up), nseg)
+    return buf.value.decode()

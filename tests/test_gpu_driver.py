@@ -131,3 +131,56 @@ def test_raw_sweeps_to_kml_matches_oracle(tmp_path):
     # and the calibrated track is a sensible answer: within a few metres of the true path's GPS fixes
     lat, lon, _ = O.parse_gprmc(gprmc, st[0], st[-1])
     assert abs(c1[:, 1].mean() - np.mean(lat)) < 1e-3 and abs(c1[:, 0].mean() - np.mean(lon)) < 1e-3
+
+
+def test_driver_gga_log_and_map_json_outputs(tmp_path):
+    """result_control 2 / 3 (Baidu BD-09 / Gaode GCJ-02 JSON, short_distance_track_process.cpp:271-291)
+    from a $GPGGA log: same numbers as the KML path, pushed through the datum shifts and createJSON."""
+    longs, shorts, gprmc = synth.segmented_run(3000, 1000, 300, 100, seed=11, dropout=0.0)
+    # the same fixes as $GPGGA sentences
+    lines = []
+    for ln in gprmc.splitlines():
+        f = ln.split(",")
+        if len(f) > 8 and f[1] == "$GPRMC":
+            lines.append("%s,$GPGGA,%s,%s,%s,%s,%s,1,08,1.0,10.0,M,8.0,M,,*5A" % (f[0], f[2], f[4], f[5], f[6], f[7]))
+        lines.append("")
+    gga = "\n".join(lines) + "\n"
+    trk, log = tmp_path / "tracks.txt", tmp_path / "gps.txt"
+    synth.write_track_file(str(trk), longs, shorts)
+    log.write_text(gga)
+    outs = {}
+    for rc in (1, 2, 3):
+        k0, k1 = tmp_path / ("ori%d" % rc), tmp_path / ("cal%d" % rc)
+        r = subprocess.run([RUN, "--gps_input_filename", str(log), "--slam_track_filename", str(trk),
+                            "--gps_original_filename", str(k0), "--gps_improved_filename", str(k1),
+                            "--result_control", str(rc), "--kml_config", "/nonexistent"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout
+        outs[rc] = (k0.read_text(), k1.read_text())
+    # oracle chain on the GGA log
+    total = []
+    for s in longs:
+        lat, lon, t = O.parse_gps_log(gga, s[0, 3], s[-1, 3])
+        enu = O.gps_to_enu(lat, lon, t, s)
+        w, _ = O.long_segment(s[:len(enu)], enu, 5)
+        total.append(np.c_[enu, w])
+    gps = np.concatenate(total)
+    acc = None
+    for s in shorts:
+        so, go, wo = O.match_gps(gps, s)
+        _, _, cal, _ = O.track_fit(so, go, wo)
+        acc = O.merge_short(acc, cal, wo)
+    ll0, _ = O.local_to_wgs(gps)
+    ll1, _ = O.local_to_wgs(acc)
+    end1, rgb1 = O.colour_segments(acc)
+    num = lambda s: np.array([float(x) for x in re.findall(r"-?\d+\.\d+(?:e-?\d+)?", s)])
+    skel = lambda s: re.sub(r"-?\d+\.\d+(?:e-?\d+)?", "N", s)
+    for rc, chain in ((3, ("gps_to_gcj",)), (2, ("gps_to_gcj", "gcj_to_bd"))):
+        a, b = ll0, ll1
+        for step in chain:
+            a, b = O.mars(a, step), O.mars(b, step)
+        ref0, ref1 = O.json_map(a, 0), O.json_map(b, 1, end1, rgb1)
+        assert skel(outs[rc][0]) == skel(ref0) and skel(outs[rc][1]) == skel(ref1)
+        assert np.abs(num(outs[rc][0]) - num(ref0)).max() < 1e-9
+        assert np.abs(num(outs[rc][1]) - num(ref1)).max() < 1e-9
+    assert outs[1][0].startswith("<?xml") and len(_kml_coords(outs[1][0])) == len(gps)

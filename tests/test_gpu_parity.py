@@ -359,3 +359,17 @@ def test_rccl_world_of_one(ctx):
     assert L.gpscal_allgather_chains(ctx._h, local.ctypes.data, counts.ctypes.data, out.ctypes.data) == 0
     assert np.array_equal(out, local)
     assert L.gpscal_comm_destroy(ctx._h) == 0
+
+
+def test_gcj_bd_transforms_match_oracle(ctx):
+    """gpscal_gps_to_gcj / gcj_to_bd / bd_to_gcj (gps_process.cc:526-595, 1127-1207) vs the oracle:
+    float64 polynomials and sines; device libm vs glibc -> 1e-12 degrees."""
+    rng = np.random.default_rng(3)
+    ll = np.c_[rng.uniform(60, 150, 5000), rng.uniform(-10, 65, 5000)]  # in and out of the China box
+    gcj = ctx.mars(ll, "gps_to_gcj")
+    assert np.abs(gcj - O.mars(ll, "gps_to_gcj")).max() < 1e-12
+    out = (ll[:, 0] < 72.004) | (ll[:, 0] > 137.8347) | (ll[:, 1] < 0.8293) | (ll[:, 1] > 55.8271)
+    assert out.any() and np.array_equal(gcj[out], ll[out])
+    bd = ctx.mars(gcj, "gcj_to_bd")
+    assert np.abs(bd - O.mars(gcj, "gcj_to_bd")).max() < 1e-12
+    assert np.abs(ctx.mars(bd, "bd_to_gcj") - O.mars(bd, "bd_to_gcj")).max() < 1e-12

@@ -402,3 +402,77 @@ def test_input_data_oracle_cuts_tracks_by_distance():
     assert len(shorts) > len(longs) >= 2
     # short tracks overlap by roughly the overlap distance
     assert any(b["first"] < a["last"] for a, b in zip(shorts, shorts[1:]))
+
+
+# ------------------------------------------------ alternate sentences and map datums
+def _gga(t, lat, lon, ok=True):
+    la, lo = abs(lat), abs(lon)
+    f = lambda v, w: ("%0" + str(w) + ".5f") % (int(v) * 100 + (v - int(v)) * 60)
+    if not ok:
+        return "%.8f,$GPGGA,044500.00,,,,,0,00,99.99,,,,,,*48" % t
+    return "%.8f,$GPGGA,044500.00,%s,%s,%s,%s,1,08,1.0,10.0,M,8.0,M,,*5A" % (
+        t, f(la, 10), "N" if lat >= 0 else "S", f(lo, 11), "E" if lon >= 0 else "W")
+
+
+def _gll(t, lat, lon, status="A"):
+    la, lo = abs(lat), abs(lon)
+    f = lambda v, w: ("%0" + str(w) + ".5f") % (int(v) * 100 + (v - int(v)) * 60)
+    return "%.8f,$GPGLL,%s,%s,%s,%s,044500.00,%s,A*6D" % (t, f(la, 10), "N" if lat >= 0 else "S", f(lo, 11),
+                                                          "E" if lon >= 0 else "W", status)
+
+
+def test_gpgga_and_gpgll_logs_parse_like_the_reference():
+    """gps_process.cc:113-159 picks the parser from the first line; GPGGA (:231-299) drops fixes
+    without coordinates, GPGLL (:300-372) keeps every line in the window, status V included."""
+    t0 = 1494650700.0
+    rows = [(t0 + k, 31.17 + 1e-4 * k, 121.39 + 2e-4 * k) for k in range(8)]
+    gga = "\n".join(_gga(t, la, lo, ok=(k != 3)) for k, (t, la, lo) in enumerate(rows)) + "\n"
+    lat, lon, t = O.parse_gps_log(gga, t0 + 1, t0 + 5)
+    assert list(t) == [t0 + k for k in (0, 1, 2, 4, 5, 6)]  # window +-1 s (long casts), line 3 has no fix
+    assert np.abs(lat - np.array([rows[k][1] for k in (0, 1, 2, 4, 5, 6)])).max() < 1e-7
+    assert np.abs(lon - np.array([rows[k][2] for k in (0, 1, 2, 4, 5, 6)])).max() < 1e-7
+    gll = "\n".join(_gll(t, -la, -lo, "V" if k == 2 else "A") for k, (t, la, lo) in enumerate(rows)) + "\n"
+    lat, lon, t = O.parse_gps_log(gll, t0 + 1, t0 + 5)
+    assert len(t) == 7 and lat[2] < 0 and lon[2] < 0  # southern / western hemisphere signs; V kept
+    assert np.abs(lat + np.array([r[1] for r in rows[:7]])).max() < 1e-7
+    # the shipped GPRMC log goes through the same entry point unchanged
+    text = open(os.path.join(GOLDEN, "original_gps_data.txt")).read()
+    a = O.parse_gps_log(text, 1494650900.0, 1494651000.0)
+    b = O.parse_gprmc(text, 1494650900.0, 1494651000.0)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and len(a[2]) > 50
+    assert len(O.parse_gps_log("1.0,$GPVTG,1,2\n", 0, 10)[2]) == 0  # unsupported sentence: nothing
+
+
+def test_gcj02_bd09_transforms():
+    """gps_process.cc:526-595, 1127-1207.  Known behaviour of the public 'Mars' offset: a few hundred
+    metres inside China, identity outside; BD-09 adds ~0.006 deg; bd_decrypt undoes bd_encrypt to ~1e-5 deg."""
+    ll = np.array([[121.398330784, 31.177944836], [116.3975, 39.9087], [2.2945, 48.8584], [139.69, 35.68]])
+    gcj = O.mars(ll, "gps_to_gcj")
+    d = gcj - ll
+    assert 1e-3 < abs(d[0, 0]) < 1e-2 and 1e-3 < abs(d[0, 1]) < 1e-2  # Shanghai: ~0.0045, ~-0.002 deg
+    assert np.array_equal(gcj[2], ll[2]) and np.array_equal(gcj[3], ll[3])  # Paris, Tokyo: outside the box
+    bd = O.mars(gcj, "gcj_to_bd")
+    assert np.all(np.abs(bd[:2] - gcj[:2] - [0.0065, 0.006]) < 2e-3)
+    back = O.mars(bd, "bd_to_gcj")
+    assert np.abs(back - gcj).max() < 2e-5
+    # independent re-derivation of one value with the reference's truncated PI
+    PI, a, ee = 3.141592653589, 6378245.0, (6378245.0 ** 2 - 6356863.0188 ** 2) / 6378245.0 ** 2
+    x, y = ll[1, 0] - 105.0, ll[1, 1] - 35.0
+    dlat = (-100.0 + 2.0 * x + 3.0 * y + 0.2 * y * y + 0.1 * x * y + 0.2 * math.sqrt(abs(x))
+            + (20.0 * math.sin(6.0 * x * PI) + 20.0 * math.sin(2.0 * x * PI)) * 2.0 / 3.0
+            + (20.0 * math.sin(y * PI) + 40.0 * math.sin(y / 3.0 * PI)) * 2.0 / 3.0
+            + (160.0 * math.sin(y / 12.0 * PI) + 320 * math.sin(y * PI / 30.0)) * 2.0 / 3.0)
+    rad = ll[1, 1] / 180.0 * PI
+    magic = 1 - ee * math.sin(rad) ** 2
+    dlat = (dlat * 180.0) / ((a * (1 - ee)) / (magic * math.sqrt(magic)) * PI)
+    assert abs(gcj[1, 1] - (ll[1, 1] + dlat)) < 1e-12
+
+
+def test_json_writer_layout():
+    """createJSON, gps_process.cc:1210-1250: precision(15), trailing commas and all."""
+    ll = np.array([[121.5, 31.25], [121.50000123456789, 31.2500009], [121.6, 31.3]])
+    assert O.json_map(ll, 0) == ('[{"line":[[121.5,31.25],[121.500001234568,31.2500009],[121.6,31.3],],'
+                                 '"color":"FF00FF"}]')
+    got = O.json_map(ll, 1, [0, 2], [0xFF0000, 0x00FF7F])
+    assert got == ('[{"line":[[121.5,31.25],],"color":"FF0000"},{"line":[[121.500001234568,31.2500009],'
+                   '[121.6,31.3],],"color":"00FF7F"},]')
