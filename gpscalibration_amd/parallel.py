@@ -54,3 +54,25 @@ def gather_segment_results(per_seg_arrays, seg_lengths_all, rank, world, dist):
         counts.append(int(np.sum(seg_lengths_all[lo:hi])))
     t = per_seg_arrays if isinstance(per_seg_arrays, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(per_seg_arrays))
     return allgather_ragged(t, counts, dist)
+
+
+def loam_run_sharded(ctx, segments, stamps, dist=None):
+    """The LOAM node chain over segments sharded in contiguous blocks across ranks (one process
+    per GPU), followed by the one exchange of SURVEY 8(e): an all-gather of the per-segment
+    /true_odometry_to_init tracks.  Every rank returns the tracks of ALL segments (list of [n,4]
+    float64), ready for the global track alignment.  dist=None runs everything on this rank."""
+    import torch
+    nseg = len(segments)
+    if dist is None or dist.get_world_size() == 1:
+        return [r["track"] for r in ctx.loam_run(segments, stamps)]
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_range(nseg, rank, world)
+    mine = ctx.loam_run(segments[lo:hi], stamps[lo:hi]) if hi > lo else []
+    lens = np.array([len(s) for s in segments])
+    local = np.concatenate([r["track"] for r in mine]) if mine else np.zeros((0, 4))
+    t = torch.from_numpy(np.ascontiguousarray(local))
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    full = gather_segment_results(t, lens, rank, world, dist).cpu().numpy()
+    starts = np.r_[0, np.cumsum(lens)]
+    return [full[starts[s]:starts[s + 1]] for s in range(nseg)]
