@@ -171,8 +171,10 @@ struct BestRing {
     int i;
     unsigned ord;
     int a0, a1, b0, b1, closest;
+    int base;  // added to the index a candidate carries (a per-ring grid numbers its points from 0)
     __device__ __forceinline__ void init(float bound2, int closest_, int a0_, int a1_, int b0_, int b1_)
     {
+        base = 0;
         d = bound2;
         i = -1;
         ord = 0u;
@@ -182,7 +184,7 @@ struct BestRing {
     __device__ __forceinline__ float worst() const { return d; }
     __device__ __forceinline__ void consider(float d2, const float4 &c, unsigned)
     {
-        const int idx = __float_as_int(c.w);
+        const int idx = __float_as_int(c.w) + base;
         const bool in = ((idx >= a0 && idx < a1) || (idx >= b0 && idx < b1)) && idx != closest;
         if (!in) return;
         const unsigned o = idx > closest ? (unsigned)(idx - closest) : 0x40000000u + (unsigned)(closest - idx);

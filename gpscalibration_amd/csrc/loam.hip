@@ -453,7 +453,7 @@ struct IterState {
     float tr[6];
     int done, degenerate, iters, nsel;
     double P[36];
-    int rs_c[18], rs_s[18], mono, pad;  // laserOdometry only: ring tables of the last clouds
+    int rs_c[18], rs_s[18], mono, ring_ok;  // laserOdometry only: ring tables of the last clouds
 };
 
 __global__ void lm_init_kernel(const MapDesc *__restrict__ sweeps, int nsweeps, const float *__restrict__ tr_in,
@@ -670,7 +670,9 @@ __global__ void iter_finish_kernel(const IterState *__restrict__ st, int nsweeps
 __global__ __launch_bounds__(PT_BLOCK) void lo_init_kernel(const SweepDesc *__restrict__ sweeps,
                                                            const float4 *__restrict__ clast,
                                                            const float4 *__restrict__ slast, int *__restrict__ corr,
-                                                           const float *__restrict__ tr_in, IterState *__restrict__ st)
+                                                           const float *__restrict__ tr_in, IterState *__restrict__ st,
+                                                           const int *__restrict__ ring_cnt_c,
+                                                           const int *__restrict__ ring_cnt_s)
 {
     const int b = blockIdx.x;
     const SweepDesc D = sweeps[b];
@@ -706,7 +708,40 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_init_kernel(const SweepDesc *__re
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) S.mono = s_mono;
+    if (threadIdx.x == 0) {
+        S.mono = s_mono;
+        // per-ring grids were built from the caller's ring counts: use them only if they describe
+        // the clouds' own ring ids
+        int ok = s_mono && ring_cnt_c && ring_cnt_s;
+        if (ok) {
+            int ac = 0, as = 0;
+            for (int r = 0; r < 16; ++r) {
+                ok = ok && S.rs_c[r] == min(ac, D.mc) && S.rs_s[r] == min(as, D.ms);
+                ac += ring_cnt_c[16 * b + r];
+                as += ring_cnt_s[16 * b + r];
+            }
+            ok = ok && ac == D.mc && as == D.ms;
+        }
+        S.ring_ok = ok;
+    }
+}
+
+// Adjacent-ring search on per-ring grids: every lane with 0 <= want <= 15 queries the grid of ring
+// `want` of its sweep; the wave visits the distinct rings one after the other (a tile of features
+// spans one or two rings).  R carries its intervals in cloud indices; a ring's grid numbers its
+// points from 0, hence R.base.
+__device__ __forceinline__ void ring_search(const PairDesc *__restrict__ rp, const float4 *__restrict__ rsorted,
+                                            const unsigned *__restrict__ rcells, const int *rs, bool has, int want,
+                                            float4 ps, BestRing &R)
+{
+    unsigned long long todo = __ballot(has && want >= 0 && want <= 15);
+    while (todo) {
+        const int r = __builtin_amdgcn_readlane(want, (int)__builtin_ctzll(todo));
+        const bool sel = has && want == r;
+        todo &= ~__ballot(sel);
+        R.base = rs[r];
+        knn_query(rp[r], rsorted, rcells, sel, ps.x, ps.y, ps.z, R);
+    }
 }
 
 __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
@@ -714,7 +749,9 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     const float4 *__restrict__ clast, const float4 *__restrict__ slast, const PairDesc *__restrict__ cpairs,
     const float4 *__restrict__ csorted, const unsigned *__restrict__ ccells, const PairDesc *__restrict__ spairs,
     const float4 *__restrict__ ssorted, const unsigned *__restrict__ scells, int *__restrict__ corr,
-    const IterState *__restrict__ st)
+    const IterState *__restrict__ st, const PairDesc *__restrict__ rcpairs, const float4 *__restrict__ rcsorted,
+    const unsigned *__restrict__ rccells, const PairDesc *__restrict__ rspairs, const float4 *__restrict__ rssorted,
+    const unsigned *__restrict__ rscells)
 {
     const int b = blockIdx.y;
     if (st[b].done) return;
@@ -731,6 +768,7 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     }
     __syncthreads();
     const bool mono = st[b].mono != 0;
+    const bool ring_grids = rcpairs != nullptr && st[b].ring_ok != 0;
     const PairDesc &CP = cpairs[b];
     const PairDesc &SP = spairs[b];
     const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off, *cl = clast + D.clast_off,
@@ -764,7 +802,13 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
             }
             BestRing R;
             R.init(25.f, closest, a0, a1, b0, b1);
-            knn_query(CP, csorted, ccells, has, ps.x, ps.y, ps.z, R);
+            if (ring_grids) {
+                const int scan = has ? (int)cl[closest].w : -9;
+                ring_search(rcpairs + 16 * b, rcsorted, rccells, s_rs_c, has && a1 > a0, scan - 1, ps, R);
+                ring_search(rcpairs + 16 * b, rcsorted, rccells, s_rs_c, has && b1 > b0, scan + 1, ps, R);
+            } else {
+                knn_query(CP, csorted, ccells, has, ps.x, ps.y, ps.z, R);
+            }
             if (has) min2 = R.i;
         } else if (has) {
             const int scan = (int)cl[closest].w;
@@ -845,9 +889,16 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
             }
             BestRing R2, R3;
             R2.init(25.f, closest, a0, a1, b0, b1);
-            knn_query(SP, ssorted, scells, has, ps.x, ps.y, ps.z, R2);
             R3.init(25.f, closest, c0, c1, e0, e1);
-            knn_query(SP, ssorted, scells, has, ps.x, ps.y, ps.z, R3);
+            if (ring_grids) {
+                const int scan = has ? (int)sl[closest].w : -9;
+                ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && (a1 > a0 || b1 > b0), scan, ps, R2);
+                ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && c1 > c0, scan - 1, ps, R3);
+                ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && e1 > e0, scan + 1, ps, R3);
+            } else {
+                knn_query(SP, ssorted, scells, has, ps.x, ps.y, ps.z, R2);
+                knn_query(SP, ssorted, scells, has, ps.x, ps.y, ps.z, R3);
+            }
             if (has) {
                 min2 = R2.i;
                 min3 = R3.i;
@@ -1098,13 +1149,41 @@ namespace gpscal {
 int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, const float4 *d_sharp,
                          const float4 *d_flat, const float4 *d_clast, const float4 *d_slast, const long long *coff,
                          const long long *soff, const float *d_tr_in, float *d_tr_out, int *d_iters, int *d_nsel,
-                         const float *d_sum_in, float *d_sum_out)
+                         const float *d_sum_in, float *d_sum_out, const int *ring_cnt_c, const int *ring_cnt_s)
 {
     // the kd-trees of the last sweep (setInputCloud, LO:538-539,1119-1120) = two grid sets
     GridSet cg, sg;
     int rc = build_grids(ctx, d_clast, 16, coff, nsweeps, 0.f, MAX_LEVELS, cg);
     if (!rc) rc = build_grids(ctx, d_slast, 16, soff, nsweeps, 0.f, MAX_LEVELS, sg);
     if (rc) return rc;
+    // one more grid per ring of each last cloud for the adjacent-ring searches (LO:613-677, 769-844)
+    GridSet rcg, rsg;
+    DevBuf<int> d_ringc, d_rings;
+    bool ring_grids = ring_cnt_c && ring_cnt_s;
+    if (ring_grids) {
+        std::vector<long long> roc((size_t)nsweeps * 16 + 1), ros((size_t)nsweeps * 16 + 1);
+        for (int b = 0; b < nsweeps && ring_grids; ++b) {
+            long long ac = coff[b], as = soff[b];
+            for (int r = 0; r < 16; ++r) {
+                roc[16 * (size_t)b + r] = ac;
+                ros[16 * (size_t)b + r] = as;
+                ac += ring_cnt_c[16 * b + r];
+                as += ring_cnt_s[16 * b + r];
+            }
+            ring_grids = ac == coff[b + 1] && as == soff[b + 1];
+        }
+        roc[(size_t)nsweeps * 16] = coff[nsweeps];
+        ros[(size_t)nsweeps * 16] = soff[nsweeps];
+        if (ring_grids) {
+            rc = build_grids(ctx, d_clast, 16, roc.data(), nsweeps * 16, 0.f, MAX_LEVELS, rcg);
+            if (!rc) rc = build_grids(ctx, d_slast, 16, ros.data(), nsweeps * 16, 0.f, MAX_LEVELS, rsg);
+            if (rc) return rc;
+            GPSCAL_HIP(ctx, d_ringc.alloc_async((size_t)nsweeps * 16, ctx->stream));
+            GPSCAL_HIP(ctx, d_rings.alloc_async((size_t)nsweeps * 16, ctx->stream));
+            GPSCAL_HIP(ctx, hipMemcpyAsync(d_ringc.p, ring_cnt_c, sizeof(int) * 16 * nsweeps, hipMemcpyHostToDevice, ctx->stream));
+            GPSCAL_HIP(ctx, hipMemcpyAsync(d_rings.p, ring_cnt_s, sizeof(int) * 16 * nsweeps, hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
     long long ext_c = 0, ext_f = 0;
     int tiles_max = 1;
     for (int b = 0; b < nsweeps; ++b) {
@@ -1120,11 +1199,12 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
     GPSCAL_HIP(ctx, corr.alloc_async((size_t)2 * ext_c + (size_t)3 * ext_f + 8, ctx->stream));
     GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, descs, sizeof(SweepDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(lo_init_kernel, dim3(nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_clast, d_slast, corr.p,
-                       d_tr_in, d_st.p);
+                       d_tr_in, d_st.p, ring_grids ? d_ringc.p : nullptr, ring_grids ? d_rings.p : nullptr);
     for (int it0 = 0; it0 < 25; it0 += 5) {  // LO:585: a search every fifth iteration (LO:592)
         hipLaunchKernelGGL(lo_search_kernel, dim3(tiles_max, nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_sharp,
                            d_flat, d_clast, d_slast, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p,
-                           sg.cell_start, corr.p, d_st.p);
+                           sg.cell_start, corr.p, d_st.p, ring_grids ? rcg.pairs.p : nullptr, rcg.sorted.p, rcg.cell_start,
+                           ring_grids ? rsg.pairs.p : nullptr, rsg.sorted.p, rsg.cell_start);
         hipLaunchKernelGGL(lo_iter_kernel, dim3(nsweeps), dim3(LBLOCK), 0, ctx->stream, d_sw.p, d_sharp, d_flat,
                            d_clast, d_slast, corr.p, d_st.p, it0);
     }

@@ -712,7 +712,10 @@ struct LoamPipe {
     InArg<float> a_xyz;
     InArg<double> a_stamps;
     DevBuf<float4> d_sharp, d_lsharp, d_flat, d_lflat;
-    DevBuf<int> d_counts;
+    DevBuf<int> d_counts, d_ring_counts;
+    std::vector<int> ring_cnt;      // nsw x 32: less-sharp / less-flat points per ring (from scanRegistration)
+    std::vector<int> last_sweep;    // per stream: the sweep whose clouds are the current "last" clouds
+    std::vector<int> hring_c, hring_s;
     DevBuf<SegState> d_state;
     DevBuf<float4> b_pool[2][2], b_frommap[2], b_stack2[2], b_stack[2], b_newq[2], b_vin[2], b_vout[2];
     DevBuf<int> b_ts[2][2], b_tc[2][2], b_ns[2], b_nc[2], b_voff[2], b_vcnt[2], b_vocnt[2];
@@ -756,14 +759,17 @@ struct LoamPipe {
         GPSCAL_HIP(ctx, d_flat.alloc((size_t)nsw * 3072));
         GPSCAL_HIP(ctx, d_lflat.alloc(npts));
         GPSCAL_HIP(ctx, d_counts.alloc((size_t)nsw * 5));
+        GPSCAL_HIP(ctx, d_ring_counts.alloc((size_t)nsw * 32));
         int sr_status = 0;
         int rc = scan_registration_device(ctx, nsw, sweep_off, sweep_off, a_xyz.dev, d_full.p, d_sharp.p, d_lsharp.p,
-                                          d_flat.p, d_lflat.p, d_counts.p, &sr_status);
+                                          d_flat.p, d_lflat.p, d_counts.p, &sr_status, d_ring_counts.p);
         if (rc) return rc;
         if (sr_status & 2) return fail(ctx, GPSCAL_ESIZE, "LOAM chain: a sweep has more than 60000 ring points");
         if (sr_status & 1) return fail(ctx, GPSCAL_ERANGE, "LOAM chain: less-flat capacity exceeded (sweep with missing rings)");
         cnt.resize((size_t)nsw * 5);
+        ring_cnt.resize((size_t)nsw * 32);
         GPSCAL_HIP(ctx, hipMemcpyAsync(cnt.data(), d_counts.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, q));
+        GPSCAL_HIP(ctx, hipMemcpyAsync(ring_cnt.data(), d_ring_counts.p, sizeof(int) * ring_cnt.size(), hipMemcpyDeviceToHost, q));
         GPSCAL_HIP(ctx, hipStreamSynchronize(q));
         for (int g = 0; g < nsw; ++g) {
             max_ls = std::max(max_ls, cnt[5 * g + 2]);
@@ -861,6 +867,9 @@ struct LoamPipe {
         cmoff.assign(nseg + 1, 0);
         smoff.assign(nseg + 1, 0);
         local_t.assign(nseg, 0);
+        last_sweep.assign(nseg, -1);
+        hring_c.assign((size_t)nseg * 16, 0);
+        hring_s.assign((size_t)nseg * 16, 0);
         frame_count.assign(nseg, 1);  // skipFrameNum, LO:495
         return GPSCAL_OK;
     }
@@ -917,6 +926,10 @@ struct LoamPipe {
             const bool matchable = act && local_t[s] >= 2;
             D.mc = matchable ? (int)(coff[s + 1] - coff[s]) : 0;
             D.ms = matchable ? (int)(soff[s + 1] - soff[s]) : 0;
+            for (int r = 0; r < 16; ++r) {
+                hring_c[16 * (size_t)s + r] = last_sweep[s] >= 0 ? ring_cnt[32 * (size_t)last_sweep[s] + r] : 0;
+                hring_s[16 * (size_t)s + r] = last_sweep[s] >= 0 ? ring_cnt[32 * (size_t)last_sweep[s] + 16 + r] : 0;
+            }
             any_match = any_match || (act && !seed);
             published[s] = act && !seed;
             any_tm = any_tm || published[s];
@@ -943,7 +956,8 @@ struct LoamPipe {
             GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr.p, 24, &S[0].lo_tr[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
             GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr2.p, 24, &S[0].lo_sum[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
             int rc = loam_odometry_device(ctx, nseg, hsw.data(), d_sharp.p, d_flat.p, d_clast[lastbuf].p, d_slast[lastbuf].p,
-                                          coff.data(), soff.data(), d_tr.p, d_tr.p, nullptr, nullptr, d_tr2.p, d_tr2.p);
+                                          coff.data(), soff.data(), d_tr.p, d_tr.p, nullptr, nullptr, d_tr2.p, d_tr2.p,
+                                          hring_c.data(), hring_s.data());
             if (rc) return rc;
             for (int s = 0; s < nseg; ++s)
                 if (published[s]) {
@@ -1023,7 +1037,10 @@ struct LoamPipe {
         GPSCAL_HIP(ctx, hipMemcpyAsync(track, d_step_track.p, sizeof(double) * 4 * nseg, hipMemcpyDeviceToHost, q));
         GPSCAL_HIP(ctx, hipStreamSynchronize(q));
         for (int s = 0; s < nseg; ++s)
-            if (sweep_idx[s] >= 0) ++local_t[s];
+            if (sweep_idx[s] >= 0) {
+                ++local_t[s];
+                last_sweep[s] = sweep_idx[s];
+            }
         return GPSCAL_OK;
     }
 

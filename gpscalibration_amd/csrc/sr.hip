@@ -91,7 +91,7 @@ __global__ __launch_bounds__(SBLOCK) void scan_registration_kernel(
     float4 *__restrict__ sharp, float4 *__restrict__ less_sharp, float4 *__restrict__ flat,
     float4 *__restrict__ less_flat, signed char *__restrict__ ringbuf, float *__restrict__ oribuf,
     float *__restrict__ curv, int *__restrict__ sort_ind, float4 *__restrict__ lfs, unsigned long long *g_keys,
-    int *g_old, int *__restrict__ counts, int *__restrict__ status)
+    int *g_old, int *__restrict__ counts, int *__restrict__ status, int *__restrict__ ring_counts)
 {
     extern __shared__ unsigned long long dyn_lds[];
     unsigned long long *lds_keys = dyn_lds;                              // LDS_KEYS
@@ -323,7 +323,13 @@ __global__ __launch_bounds__(SBLOCK) void scan_registration_kernel(
 
     // ---- picking, ring by ring and sector by sector (SR:558-674)
     for (int ring = 0; ring < N_RINGS; ++ring) {
-        if (threadIdx.x == 0) s_nl = 0;
+        if (threadIdx.x == 0) {
+            s_nl = 0;
+            if (ring_counts) {  // less-sharp / less-flat points emitted by this ring index so far
+                ring_counts[32 * b + ring] = -S.counts[2];
+                ring_counts[32 * b + 16 + ring] = -S.counts[4];
+            }
+        }
         __syncthreads();
         for (int j = 0; j < 6; ++j) {
             const int sp = (S.scan_start[ring] * (6 - j) + S.scan_end[ring] * j) / 6;
@@ -438,6 +444,10 @@ __global__ __launch_bounds__(SBLOCK) void scan_registration_kernel(
         __syncthreads();
         block_voxel_grid(S, lf, nl, 0.2f, o_lflat, D.lf_cap, &S.counts[4], lds_keys, gk, D.key_cap);  // SR:667-673
         __syncthreads();
+        if (threadIdx.x == 0 && ring_counts) {
+            ring_counts[32 * b + ring] += S.counts[2];
+            ring_counts[32 * b + 16 + ring] += S.counts[4];
+        }
     }
     if (threadIdx.x == 0) {
         S.counts[0] = cs;
@@ -456,7 +466,7 @@ namespace gpscal {
 
 int scan_registration_device(gpscal_ctx *ctx, int nsweeps, const int *xyz_off, const int *lfo, const float *d_xyz,
                              float4 *d_full, float4 *d_sharp, float4 *d_lsharp, float4 *d_flat, float4 *d_lflat,
-                             int *d_counts, int *status)
+                             int *d_counts, int *status, int *d_ring_counts)
 {
     std::vector<SrDesc> hd(nsweeps);
     long long key_total = 0;
@@ -500,7 +510,7 @@ int scan_registration_device(gpscal_ctx *ctx, int nsweeps, const int *xyz_off, c
     }
     hipLaunchKernelGGL(scan_registration_kernel, dim3(nsweeps), dim3(SBLOCK), sr_dyn_lds(), ctx->stream, d_desc.p,
                        d_xyz, d_full, d_sharp, d_lsharp, d_flat, d_lflat, d_ring.p, d_ori.p, d_curv.p, d_sid.p, d_lfs.p,
-                       d_keys.p, d_old.p, d_counts, d_status.p);
+                       d_keys.p, d_old.p, d_counts, d_status.p, d_ring_counts);
     GPSCAL_HIP(ctx, hipGetLastError());
     GPSCAL_HIP(ctx, hipMemcpyAsync(status, d_status.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -534,7 +544,7 @@ extern "C" int gpscal_scan_registration_batched(gpscal_ctx *ctx, int nsweeps, co
     int rc = scan_registration_device(ctx, nsweeps, xyz_off, lfo, a_in.dev, reinterpret_cast<float4 *>(o_full.dev),
                                       reinterpret_cast<float4 *>(o_sh.dev), reinterpret_cast<float4 *>(o_ls.dev),
                                       reinterpret_cast<float4 *>(o_fl.dev), reinterpret_cast<float4 *>(o_lf.dev),
-                                      o_cnt.dev, &st);
+                                      o_cnt.dev, &st, nullptr);
     if (rc) return rc;
     bool sync = true;
     GPSCAL_HIP(ctx, o_full.commit(ctx, &sync));
