@@ -686,6 +686,23 @@ __global__ __launch_bounds__(SBLOCK) void lm_rebuild_kernel(SegState *__restrict
     }
 }
 
+// moves laserOdometry's transform / transformSum between SegState and the flat arrays the loop
+// kernels take; store: only streams that published take the results
+__global__ void lo_state_kernel(SegState *__restrict__ st, int nseg, float *__restrict__ tr, float *__restrict__ sum,
+                                const int *__restrict__ rows, int store)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseg * 6) return;
+    const int s = i / 6, k = i - 6 * s;
+    if (!store) {
+        tr[i] = st[s].lo_tr[k];
+        sum[i] = st[s].lo_sum[k];
+    } else if (rows[s] >= 0) {
+        st[s].lo_tr[k] = tr[i];
+        st[s].lo_sum[k] = sum[i];
+    }
+}
+
 __global__ void lm_flip_kernel(SegState *__restrict__ st, int nseg)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -953,17 +970,12 @@ struct LoamPipe {
             // transform / transformSum live in SegState; the kernels take flat [nstream][6] arrays.  A
             // stream that idles or seeds has empty clouds here: its state passes through unchanged
             // (zero transform accumulates to itself only for a zero sum, so those rows are restored).
-            GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr.p, 24, &S[0].lo_tr[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
-            GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr2.p, 24, &S[0].lo_sum[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
+            hipLaunchKernelGGL(lo_state_kernel, dim3(div_up(nseg * 6, 64)), dim3(64), 0, q, S, nseg, d_tr.p, d_tr2.p, d_rows.p, 0);
             int rc = loam_odometry_device(ctx, nseg, hsw.data(), d_sharp.p, d_flat.p, d_clast[lastbuf].p, d_slast[lastbuf].p,
                                           coff.data(), soff.data(), d_tr.p, d_tr.p, nullptr, nullptr, d_tr2.p, d_tr2.p,
                                           hring_c.data(), hring_s.data());
             if (rc) return rc;
-            for (int s = 0; s < nseg; ++s)
-                if (published[s]) {
-                    GPSCAL_HIP(ctx, hipMemcpyAsync(&S[s].lo_tr[0], d_tr.p + 6 * s, 24, hipMemcpyDeviceToDevice, q));
-                    GPSCAL_HIP(ctx, hipMemcpyAsync(&S[s].lo_sum[0], d_tr2.p + 6 * s, 24, hipMemcpyDeviceToDevice, q));
-                }
+            hipLaunchKernelGGL(lo_state_kernel, dim3(div_up(nseg * 6, 64)), dim3(64), 0, q, S, nseg, d_tr.p, d_tr2.p, d_rows.p, 1);
         }
         {
             const int gx = std::max(1, std::min(div_up(std::max(max_ls + max_lf, 1), 256), 64));
