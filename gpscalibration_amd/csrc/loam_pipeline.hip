@@ -1081,36 +1081,56 @@ extern "C" int gpscal_loam_run_batched(gpscal_ctx *ctx, int nseg, const float *x
     GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
     const int nsw = seg_sweep_off[nseg] - seg_sweep_off[0];
     if (nsw < 1 || seg_sweep_off[0] != 0) return fail(ctx, GPSCAL_EINVAL, "gpscal_loam_run_batched: bad segment offsets");
-    int tmax = 0;
-    for (int s = 0; s < nseg; ++s) {
+    for (int s = 0; s < nseg; ++s)
         if (seg_sweep_off[s + 1] < seg_sweep_off[s]) return fail(ctx, GPSCAL_EINVAL, "gpscal_loam_run_batched: bad segment offsets");
-        tmax = std::max(tmax, seg_sweep_off[s + 1] - seg_sweep_off[s]);
-    }
-    LoamPipe P;
-    int rc = P.init(ctx, nseg, xyz, sweep_off, nsw, stamps, corner_pool_cap, surf_pool_cap);
-    if (rc) return rc;
-    std::vector<int> idx(nseg), pub(nseg), mapd(nseg), its(nseg);
-    std::vector<float> lo((size_t)nseg * 6), lm((size_t)nseg * 6), tm((size_t)nseg * 6);
-    std::vector<double> tr((size_t)nseg * 4);
+    // Segments are independent, so they run in groups sized to the free HBM: a stream holds its map
+    // pools, filter scratch and packed clouds (~200 MB at the default pool capacities).
+    const long long c0 = corner_pool_cap > 0 ? corner_pool_cap : 1 << 18, c1 = surf_pool_cap > 0 ? surf_pool_cap : 1 << 20;
+    const double per_stream = 16.0 * 10.5 * (double)(c0 + c1);  // bytes, see LoamPipe::init
+    size_t free_b = 0, total_b = 0;
+    GPSCAL_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    int group = (int)std::max(1.0, std::min((double)nseg, 0.6 * (double)free_b / per_stream));
+    if (const char *e = getenv("GPSCAL_LOAM_GROUP")) group = std::max(1, std::min(nseg, atoi(e)));
     const float fnan = std::nanf("");
     const double dnan = std::nan("");
-    for (int t = 0; t < tmax; ++t) {
-        for (int s = 0; s < nseg; ++s) idx[s] = t < seg_sweep_off[s + 1] - seg_sweep_off[s] ? seg_sweep_off[s] + t : -1;
-        rc = P.step(idx.data(), pub.data(), mapd.data(), lo.data(), lm.data(), tm.data(), tr.data(), its.data());
+    for (int s0 = 0; s0 < nseg; s0 += group) {
+        const int ng = std::min(group, nseg - s0);
+        const int w0 = seg_sweep_off[s0], w1 = seg_sweep_off[s0 + ng], nw = w1 - w0;
+        if (nw < 1) continue;
+        // the group's sweeps, offsets rebased to its first point
+        std::vector<int> off(nw + 1);
+        for (int k = 0; k <= nw; ++k) off[k] = sweep_off[w0 + k] - sweep_off[w0];
+        int gmax = 0;
+        for (int s = 0; s < ng; ++s) gmax = std::max(gmax, seg_sweep_off[s0 + s + 1] - seg_sweep_off[s0 + s]);
+        LoamPipe P;
+        int rc = P.init(ctx, ng, xyz + 3 * (size_t)sweep_off[w0], off.data(), nw, stamps + w0, corner_pool_cap, surf_pool_cap);
         if (rc) return rc;
-        for (int s = 0; s < nseg; ++s) {
-            const int g = idx[s];
-            if (g < 0) continue;
-            for (int k = 0; k < 6; ++k) {
-                if (lo_sum_out) lo_sum_out[6 * (size_t)g + k] = lo[6 * s + k];
-                if (lm_aft_out) lm_aft_out[6 * (size_t)g + k] = mapd[s] ? lm[6 * s + k] : fnan;
-                if (tm_mapped_out) tm_mapped_out[6 * (size_t)g + k] = pub[s] ? tm[6 * s + k] : fnan;
+        std::vector<int> idx(ng), pub(ng), mapd(ng), its(ng);
+        std::vector<float> lo((size_t)ng * 6), lm((size_t)ng * 6), tm((size_t)ng * 6);
+        std::vector<double> tr((size_t)ng * 4);
+        for (int t = 0; t < gmax; ++t) {
+            for (int s = 0; s < ng; ++s) {
+                const int a0 = seg_sweep_off[s0 + s], a1 = seg_sweep_off[s0 + s + 1];
+                idx[s] = t < a1 - a0 ? a0 + t - w0 : -1;
             }
-            for (int k = 0; k < 4; ++k) track_xyzt[4 * (size_t)g + k] = pub[s] ? tr[4 * s + k] : dnan;
-            if (lm_iters_out) lm_iters_out[g] = mapd[s] ? its[s] : -1;
+            rc = P.step(idx.data(), pub.data(), mapd.data(), lo.data(), lm.data(), tm.data(), tr.data(), its.data());
+            if (rc) return rc;
+            for (int s = 0; s < ng; ++s) {
+                if (idx[s] < 0) continue;
+                const size_t g = (size_t)idx[s] + w0;
+                for (int k = 0; k < 6; ++k) {
+                    if (lo_sum_out) lo_sum_out[6 * g + k] = lo[6 * s + k];
+                    if (lm_aft_out) lm_aft_out[6 * g + k] = mapd[s] ? lm[6 * s + k] : fnan;
+                    if (tm_mapped_out) tm_mapped_out[6 * g + k] = pub[s] ? tm[6 * s + k] : fnan;
+                }
+                for (int k = 0; k < 4; ++k) track_xyzt[4 * g + k] = pub[s] ? tr[4 * s + k] : dnan;
+                if (lm_iters_out) lm_iters_out[g] = mapd[s] ? its[s] : -1;
+            }
         }
+        rc = P.finish();
+        if (rc) return rc;
     }
-    return P.finish();
+    return GPSCAL_OK;
 }
 
 // input_data's replay + segmentation (input_data.cpp:78-124, 266-444) for nbag independent bags and

@@ -44,6 +44,16 @@ def test_loam_run_two_segments_match_oracle(ctx):
     sw_a, st_a, truth_a = synth.drive(W, 30, seed=1, n_az=900)
     sw_b, st_b, _ = synth.drive(W, 21, seed=2, n_az=900, start=(150.0, 1.0), yaw0=0.1, speed=5.0)
     got = ctx.loam_run([sw_a, sw_b], [st_a, st_b])
+    # segments never interact: running them one group at a time (what a batch larger than the free HBM
+    # does) gives the same bits
+    import os
+    os.environ["GPSCAL_LOAM_GROUP"] = "1"
+    try:
+        one_by_one = ctx.loam_run([sw_a, sw_b], [st_a, st_b])
+    finally:
+        del os.environ["GPSCAL_LOAM_GROUP"]
+    for g, h in zip(got, one_by_one):
+        assert all(np.array_equal(g[k], h[k], equal_nan=True) for k in g)
     ref_a, ref_b = O.loam_run(sw_a, st_a), O.loam_run(sw_b, st_b)
     _check(got[0], ref_a, 30)
     _check(got[1], ref_b, 21)
