@@ -53,10 +53,11 @@ def load():
     # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64 / librccl.  Two HIP
     # runtimes in one process do not coexist (the second sees no GPU), so when torch is
     # installed its copies must be the ones the process binds first.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    if not os.environ.get("GPSCAL_NO_TORCH"):  # debugging aid: bind the system HIP runtime instead
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(path)
     vp, i, dp, fp, ip = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p
     L.gpscal_strerror.restype = C.c_char_p

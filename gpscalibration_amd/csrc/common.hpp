@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -56,6 +57,14 @@ inline bool is_device_ptr(const void *ptr)
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
+// GPSCAL_POISON=1 fills every fresh device allocation with 0xAB: a result that changes under it
+// reads memory nobody wrote (debug aid)
+inline bool poison()
+{
+    static const bool on = getenv("GPSCAL_POISON") != nullptr;
+    return on;
+}
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -82,7 +91,10 @@ struct DevBuf {
         if (count == 0) count = 1;
         pooled = false;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
-        if (e == hipSuccess) n = count;
+        if (e == hipSuccess) {
+            n = count;
+            if (poison()) (void)hipMemset(p, 0xAB, count * sizeof(T));
+        }
         return e;
     }
     // Stream-ordered allocation from the device pool: for per-call temporaries.  Freed in
@@ -94,8 +106,11 @@ struct DevBuf {
         pooled = true;
         pool_stream = stream;
         hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&p), count * sizeof(T), stream);
-        if (e == hipSuccess) n = count;
-        else pooled = false;
+        if (e == hipSuccess) {
+            n = count;
+            if (poison()) (void)hipMemsetAsync(p, 0xAB, count * sizeof(T), stream);
+        } else
+            pooled = false;
         return e;
     }
 };

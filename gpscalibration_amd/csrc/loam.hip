@@ -678,7 +678,7 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_init_kernel(const SweepDesc *__re
     const SweepDesc D = sweeps[b];
     IterState &S = st[b];
     __shared__ int s_mono;
-    int *ci1 = corr + 2 * D.sharp_off + 3 * D.flat_off;
+    int *ci1 = corr + D.corr_off;
     for (int i = threadIdx.x; i < 2 * D.nc + 3 * D.ns; i += PT_BLOCK) ci1[i] = -1;
     if (threadIdx.x < 6) S.tr[threadIdx.x] = tr_in[6 * b + threadIdx.x];
     if (threadIdx.x < 36) S.P[threadIdx.x] = (threadIdx.x % 7 == 0) ? 1.0 : 0.0;
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     const PairDesc &SP = spairs[b];
     const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off, *cl = clast + D.clast_off,
                  *sl = slast + D.slast_off;
-    int *ci1 = corr + 2 * D.sharp_off + 3 * D.flat_off, *ci2 = ci1 + D.nc;
+    int *ci1 = corr + D.corr_off, *ci2 = ci1 + D.nc;
     int *si1 = ci2 + D.nc, *si2 = si1 + D.ns, *si3 = si2 + D.ns;
     // forward ring scans are bounded by the CURRENT sweep's feature counts (LO:620,776)
     const int fwd_c = min(D.nc, D.mc), fwd_s = min(D.ns, D.ms);
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(LBLOCK) void lo_iter_kernel(
     const SweepDesc D = sweeps[b];
     const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off, *cl = clast + D.clast_off,
                  *sl = slast + D.slast_off;
-    const int *ci1 = corr + 2 * D.sharp_off + 3 * D.flat_off, *ci2 = ci1 + D.nc;
+    const int *ci1 = corr + D.corr_off, *ci2 = ci1 + D.nc;
     const int *si1 = ci2 + D.nc, *si2 = si1 + D.ns, *si3 = si2 + D.ns;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 6) tr[threadIdx.x] = S.tr[threadIdx.x];
@@ -1153,13 +1153,11 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
 {
     // the kd-trees of the last sweep (setInputCloud, LO:538-539,1119-1120) = two grid sets
     GridSet cg, sg;
-    cg.pooled = sg.pooled = true;
     int rc = build_grids(ctx, d_clast, 16, coff, nsweeps, 0.f, MAX_LEVELS, cg);
     if (!rc) rc = build_grids(ctx, d_slast, 16, soff, nsweeps, 0.f, MAX_LEVELS, sg);
     if (rc) return rc;
     // one more grid per ring of each last cloud for the adjacent-ring searches (LO:613-677, 769-844)
     GridSet rcg, rsg;
-    rcg.pooled = rsg.pooled = true;
     DevBuf<int> d_ringc, d_rings;
     bool ring_grids = ring_cnt_c && ring_cnt_s;
     if (ring_grids) {
@@ -1186,19 +1184,23 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
             GPSCAL_HIP(ctx, hipMemcpyAsync(d_rings.p, ring_cnt_s, sizeof(int) * 16 * nsweeps, hipMemcpyHostToDevice, ctx->stream));
         }
     }
-    long long ext_c = 0, ext_f = 0;
+    // correspondence indices (ci1, ci2 | si1, si2, si3) live in one region per entry of `descs`: two
+    // entries may name the same sweep (two replay passes of one bag at the same message)
+    std::vector<SweepDesc> hd(descs, descs + nsweeps);
+    long long corr_total = 0;
     int tiles_max = 1;
     for (int b = 0; b < nsweeps; ++b) {
-        ext_c = std::max(ext_c, descs[b].sharp_off + descs[b].nc);
-        ext_f = std::max(ext_f, descs[b].flat_off + descs[b].ns);
-        tiles_max = std::max(tiles_max, div_up(descs[b].nc, PT_BLOCK) + div_up(descs[b].ns, PT_BLOCK));
+        hd[b].corr_off = corr_total;
+        corr_total += 2ll * hd[b].nc + 3ll * hd[b].ns;
+        tiles_max = std::max(tiles_max, div_up(hd[b].nc, PT_BLOCK) + div_up(hd[b].ns, PT_BLOCK));
     }
     DevBuf<SweepDesc> d_sw;
     DevBuf<IterState> d_st;
     DevBuf<int> corr;
     GPSCAL_HIP(ctx, d_sw.alloc_async(nsweeps, ctx->stream));
     GPSCAL_HIP(ctx, d_st.alloc_async(nsweeps, ctx->stream));
-    GPSCAL_HIP(ctx, corr.alloc_async((size_t)2 * ext_c + (size_t)3 * ext_f + 8, ctx->stream));
+    GPSCAL_HIP(ctx, corr.alloc_async((size_t)corr_total + 8, ctx->stream));
+    descs = hd.data();
     GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, descs, sizeof(SweepDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(lo_init_kernel, dim3(nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_clast, d_slast, corr.p,
                        d_tr_in, d_st.p, ring_grids ? d_ringc.p : nullptr, ring_grids ? d_rings.p : nullptr);
@@ -1285,7 +1287,6 @@ int loam_mapping_device(gpscal_ctx *ctx, int nsweeps, const MapDesc *descs, cons
 {
     // kdtreeCornerFromMap / kdtreeSurfFromMap (setInputCloud, LM:749-750) = two grid sets
     GridSet cg, sg;
-    cg.pooled = sg.pooled = true;
     int rc = build_grids(ctx, d_cmap, 16, cmoff, nsweeps, 0.f, MAX_LEVELS, cg);
     if (!rc) rc = build_grids(ctx, d_smap, 16, smoff, nsweeps, 0.f, MAX_LEVELS, sg);
     if (rc) return rc;

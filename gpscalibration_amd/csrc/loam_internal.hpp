@@ -9,6 +9,7 @@ namespace gpscal {
 
 struct SweepDesc {
     long long sharp_off, flat_off, clast_off, slast_off;  // into the float4 arrays
+    long long corr_off;                                   // filled by loam_odometry_device
     int nc, ns, mc, ms;
 };
 
