@@ -102,3 +102,39 @@ def test_input_data_segmentation_matches_oracle(ctx):
     shorts = [t for t in ref if t["flag"] == 1 and t["bag"] == 0]
     assert len(longs) >= 2 and len(shorts) >= 3
     assert any(b["first"] <= a["last"] - 2 for a, b in zip(shorts, shorts[1:]))
+
+
+def test_loam_chain_error_paths(ctx):
+    """Negative codes instead of exit() / faults: bad offsets, undersized map pools, undersized
+    output capacity, a sweep above POINTSNUM."""
+    from gpscalibration_amd import GpscalError, _lib
+    import ctypes as C
+    W = synth.lidar_world(0)
+    sw, st, _ = synth.drive(W, 12, seed=1, n_az=450)
+    # a map that outgrows its pool is reported, not silently truncated
+    with pytest.raises(GpscalError) as e:
+        ctx.loam_run([sw], [st], corner_pool_cap=64, surf_pool_cap=256)
+    assert e.value.code == -4  # GPSCAL_ENOMEM
+    # the same drive runs with sane pools afterwards (the context survives the error)
+    ok = ctx.loam_run([sw], [st], corner_pool_cap=1 << 14, surf_pool_cap=1 << 16)[0]
+    assert np.isfinite(ok["track"][1:]).all()
+    # input_data_run: distances must satisfy long > short > overlap > 0 (input_data.cpp:235-247)
+    with pytest.raises(GpscalError) as e:
+        ctx.input_data_run([sw], [st], 10.0, 20.0, 5.0)
+    assert e.value.code == -1
+    # scanRegistration refuses a sweep that keeps more ring points than the reference's arrays hold
+    big = np.tile(sw[0], (12, 1))[:62000]
+    assert len(big) == 62000
+    with pytest.raises(GpscalError) as e:
+        ctx.scan_registration([big])
+    assert e.value.code == -5  # GPSCAL_ESIZE
+    # segment offsets that run backwards
+    L = _lib.load()
+    xyz = np.ascontiguousarray(sw[0])
+    off = np.array([0, len(xyz)], dtype=np.int32)
+    seg = np.array([0, 1, 0], dtype=np.int32)
+    stamps = np.array([1.0], dtype=np.float64)
+    track = np.zeros((1, 4))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = L.gpscal_loam_run_batched(ctx._h, 2, p(xyz), p(off), p(seg), p(stamps), None, None, None, p(track), None, 0, 0)
+    assert rc == -1
