@@ -351,7 +351,8 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
     const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
     const float4 *__restrict__ nbr, const float2 *__restrict__ pt_r2, const unsigned *__restrict__ cell_start,
     const float *__restrict__ pose32, int *__restrict__ nn_idx, float *__restrict__ nn_sqd,
-    float4 *__restrict__ warm_q, float2 *__restrict__ warm_r2, double *__restrict__ partials, int nblk, int diag)
+    float4 *__restrict__ warm_q, unsigned *__restrict__ warm_r2, double *__restrict__ partials, int nblk, int diag,
+    int write_nn)
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
     __shared__ double wsum[BLOCK / 64][NACC];
@@ -382,7 +383,10 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
             // three coalesced streams: the point, last iteration's neighbour, its radii
             s = src4[P.src_off + i];
             wq = warm_q[P.src_off + i];
-            wr2 = warm_r2[P.src_off + i];
+            // both radii in one word: the upper 16 bits of each float (truncation only shrinks a radius,
+            // which keeps the certificates valid)
+            const unsigned pr = warm_r2[P.src_off + i];
+            wr2 = make_float2(__uint_as_float(pr & 0xffff0000u), __uint_as_float(pr << 16));
         }
         bool ok = valid && finite3(s.x, s.y, s.z);
         const float px = __fmaf_rn(r00, s.x, __fmaf_rn(r01, s.y, __fmaf_rn(r02, s.z, tx)));
@@ -416,11 +420,14 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
             nq = B.pos < BestQ::LIST ? sorted[B.pos]
                                      : nbr[4 * (P.tgt_off + __float_as_int(wq.w)) + (B.pos - BestQ::LIST)];
             warm_q[P.src_off + i] = nq;
-            warm_r2[P.src_off + i] = pt_r2[P.tgt_off + B.index()];
+            const float2 r2 = pt_r2[P.tgt_off + B.index()];
+            warm_r2[P.src_off + i] = (__float_as_uint(r2.x) & 0xffff0000u) | (__float_as_uint(r2.y) >> 16);
         }
         const float bd = B.dist2();
-        nn_idx[P.src_off + i] = ok ? B.index() : -1;
-        nn_sqd[P.src_off + i] = ok ? bd : INFINITY;
+        if (write_nn) {  // the correspondences are an output of the run's last iteration only
+            nn_idx[P.src_off + i] = ok ? B.index() : -1;
+            nn_sqd[P.src_off + i] = ok ? bd : INFINITY;
+        }
         if (!ok) continue;
         const double dpx = px, dpy = py, dpz = pz, qx = nq.x, qy = nq.y, qz = nq.z;
         if (WEIGHTED) {
@@ -553,12 +560,12 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const PairDesc *__restric
     }
 }
 
-__global__ void fill_warm_kernel(float4 *__restrict__ warm_q, float2 *__restrict__ warm_r2, long long n)
+__global__ void fill_warm_kernel(float4 *__restrict__ warm_q, unsigned *__restrict__ warm_r2, long long n)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     warm_q[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));  // index INT_MAX = no warm start
-    warm_r2[i] = make_float2(0.f, 0.f);
+    warm_r2[i] = 0u;
 }
 
 __global__ void pose_to_f32_kernel(const double *__restrict__ pose64, float *__restrict__ pose32, int npairs)
@@ -804,7 +811,7 @@ struct gpscal_scan_batch {
     DevBuf<int> nn_idx;
     DevBuf<float> nn_sqd;
     DevBuf<float4> warm_q;  // warm start: last iteration's neighbour (xyz + index bits) per source point
-    DevBuf<float2> warm_r2; // ... and its certified radii (r_a^2, r_b^2)
+    DevBuf<unsigned> warm_r2;  // ... and its certified radii (r_a^2, r_b^2), 16 bits each (truncated floats)
     DevBuf<double> partials, pose64, err_hist;
     DevBuf<float> pose32;
     int err_cap = 0;
@@ -1019,7 +1026,7 @@ extern "C" int gpscal_scan_batch_set_pose(gpscal_scan_batch *B, const double *T0
     return GPSCAL_OK;
 }
 
-static void launch_step(gpscal_scan_batch *B)
+static void launch_step(gpscal_scan_batch *B, bool last)
 {
     gpscal_ctx *ctx = B->ctx;
     GridSet &G = *B->tgt;
@@ -1028,7 +1035,7 @@ static void launch_step(gpscal_scan_batch *B)
     hipLaunchKernelGGL((icp_step_kernel<QPT, W>), dim3(B->nblk), dim3(BLOCK), 0, ctx->stream, B->pairs.p,     \
                        B->blk_pair.p, B->blk_first.p, B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p,  \
                        G.cell_start, B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p,        \
-                       B->partials.p, B->nblk, B->diag)
+                       B->partials.p, B->nblk, B->diag, last ? 1 : 0)
     if (B->weighted) {
         if (B->qpt == 4) STEP(4, true); else STEP(1, true);
     } else {
@@ -1069,7 +1076,7 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
         for (auto &e : ev) GPSCAL_HIP(ctx, hipEventCreate(&e));
         for (int it = 0; it < iters; ++it) {
             GPSCAL_HIP(ctx, hipEventRecord(ev[2 * it], ctx->stream));
-            launch_step(B);
+            launch_step(B, it == iters - 1);
             GPSCAL_HIP(ctx, hipEventRecord(ev[2 * it + 1], ctx->stream));
             launch_solve(B, it);
         }
@@ -1086,7 +1093,7 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
             hipGraph_t g = nullptr;
             GPSCAL_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
             for (int it = 0; it < iters; ++it) {
-                launch_step(B);
+                launch_step(B, it == iters - 1);
                 launch_solve(B, it);
             }
             GPSCAL_HIP(ctx, hipStreamEndCapture(ctx->stream, &g));
