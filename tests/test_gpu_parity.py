@@ -211,6 +211,35 @@ def test_icp_full_size_properties(ctx):
     sb.close()
 
 
+@pytest.mark.parametrize("n", [262144, 1048576])
+def test_icp_largest_config_sizes(ctx, n):
+    """BASELINE configs[3] / [4] sizes (262 144 and 1 048 576 points per scan, 20 iterations): the
+    oracle cannot run whole pairs of this size in seconds, so the check is by size-independent
+    properties -- convergence to the generating transform, a proper rotation, and exactness of a
+    random sample of the final correspondences and of stand-alone k = 3 searches against brute force."""
+    tgt, src, T_true = synth.scan_pair(n, 1)
+    off = np.array([0, n], dtype=np.int64)
+    sb = ctx.scan_batch(tgt, off, src, off)
+    T, err, _ = sb.icp(20)
+    assert err[0, -1] < 0.05 < err[0, 0]
+    assert np.abs(T[0][:3, :3] - T_true[:3, :3]).max() < 1e-3
+    assert np.abs(T[0][:3, 3] - T_true[:3, 3]).max() < 0.02
+    assert abs(np.linalg.det(T[0][:3, :3]) - 1) < 1e-9
+    sb.set_pose(T[0][None])
+    sb.icp(1)
+    idx, sqd = sb.correspondences()
+    sel = np.random.default_rng(n).choice(n, 1500, replace=False)
+    ridx, rsqd = O.knn_brute(tgt, O.transform_f32(T[0], src[sel]), 1)
+    assert np.array_equal(idx[sel], ridx[:, 0]) and np.array_equal(sqd[sel], rsqd[:, 0])
+    sb.close()
+    index = ctx.knn_index(tgt)
+    q = src[sel[:500]] + np.float32(0.3)
+    gi, gd = index.search(q, 3)
+    ri, rd = O.knn_brute(tgt, q, 3)
+    assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
+    index.close()
+
+
 # -------------------------------------------------------------------- track
 def _segments(nseg, poses, seed, dropout=0.0):
     d = synth.track_segments(nseg, poses, seed=seed, dropout=dropout)
