@@ -28,8 +28,6 @@ struct BlockShared {
     // voxel grid
     float red[SWAVES][6];
     int vg_minb[3], vg_mul[3], vg_copy, vg_m;
-    float vg_inv;
-    int run_total;
 };
 
 // rank of this thread among the threads with flag set (thread order), and the block total

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(PT_BLOCK) void lm_point_kernel(
     const float4 *__restrict__ cmap, const float4 *__restrict__ smap, const PairDesc *__restrict__ cpairs,
     const float4 *__restrict__ csorted, const unsigned *__restrict__ ccells, const PairDesc *__restrict__ spairs,
     const float4 *__restrict__ ssorted, const unsigned *__restrict__ scells, const IterState *__restrict__ st,
-    double *__restrict__ partial, int tiles_max)
+    double *__restrict__ partial, int tiles_max, int *__restrict__ prev5, long long surf_base)
 {
     const int b = blockIdx.y;
     if (st[b].done) return;
@@ -523,7 +523,22 @@ __global__ __launch_bounds__(PT_BLOCK) void lm_point_kernel(
         const float4 ps = lm_to_map(g, po);
         Best<5> B;
         B.init();
+        // last iteration's five neighbours first: the transform moved the query only a little, so they
+        // bound the search to one grid level (the result is the exact k-NN either way)
+        int *pv = prev5 + 5 * (D.cstack_off + i);
+        if (act && pv[0] >= 0) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int pj = pv[j];
+                const float4 c = cm[pj];
+                B.consider(sqdist(ps.x, ps.y, ps.z, c.x, c.y, c.z), make_float4(c.x, c.y, c.z, __int_as_float(pj)), 0u);
+            }
+        }
         knn_query(cpairs[b], csorted, ccells, act, ps.x, ps.y, ps.z, B);
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) pv[j] = B.i[4] == 0x7fffffff ? -1 : B.i[j];
+        }
         if (act && B.d[4] < 1.0f) {
             float4 q[5];
 #pragma unroll
@@ -578,7 +593,20 @@ __global__ __launch_bounds__(PT_BLOCK) void lm_point_kernel(
         const float4 ps = lm_to_map(g, po);
         Best<5> B;
         B.init();
+        int *pv = prev5 + 5 * (surf_base + D.sstack_off + i);  // the surf entries follow the corner entries
+        if (act && pv[0] >= 0) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int pj = pv[j];
+                const float4 c = sm[pj];
+                B.consider(sqdist(ps.x, ps.y, ps.z, c.x, c.y, c.z), make_float4(c.x, c.y, c.z, __int_as_float(pj)), 0u);
+            }
+        }
         knn_query(spairs[b], ssorted, scells, act, ps.x, ps.y, ps.z, B);
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) pv[j] = B.i[4] == 0x7fffffff ? -1 : B.i[j];
+        }
         if (act && B.d[4] < 1.0f) {
             float4 q[5];
 #pragma unroll
@@ -1293,9 +1321,16 @@ int loam_mapping_device(gpscal_ctx *ctx, int nsweeps, const MapDesc *descs, cons
     DevBuf<MapDesc> d_sw;
     DevBuf<IterState> d_st;
     DevBuf<double> d_part;
+    DevBuf<int> d_prev5;  // last iteration's five neighbours of every stacked feature
     int tiles_max = 1;
-    for (int b = 0; b < nsweeps; ++b)
+    long long ext_c = 0, ext_s = 0;
+    for (int b = 0; b < nsweeps; ++b) {
         tiles_max = std::max(tiles_max, div_up(descs[b].nc, PT_BLOCK) + div_up(descs[b].ns, PT_BLOCK));
+        ext_c = std::max(ext_c, descs[b].cstack_off + descs[b].nc);
+        ext_s = std::max(ext_s, descs[b].sstack_off + descs[b].ns);
+    }
+    GPSCAL_HIP(ctx, d_prev5.alloc_async((size_t)(ext_c + ext_s) * 5 + 8, ctx->stream));
+    GPSCAL_HIP(ctx, hipMemsetAsync(d_prev5.p, 0xff, sizeof(int) * ((size_t)(ext_c + ext_s) * 5 + 8), ctx->stream));
     GPSCAL_HIP(ctx, d_sw.alloc_async(nsweeps, ctx->stream));
     GPSCAL_HIP(ctx, d_st.alloc_async(nsweeps, ctx->stream));
     GPSCAL_HIP(ctx, d_part.alloc_async((size_t)nsweeps * tiles_max * LSUMS, ctx->stream));
@@ -1305,7 +1340,7 @@ int loam_mapping_device(gpscal_ctx *ctx, int nsweeps, const MapDesc *descs, cons
     for (int it = 0; it < 10; ++it) {  // LM:752; converged sweeps return at once
         hipLaunchKernelGGL(lm_point_kernel, dim3(tiles_max, nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_cstack,
                            d_sstack, d_cmap, d_smap, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p,
-                           sg.cell_start, d_st.p, d_part.p, tiles_max);
+                           sg.cell_start, d_st.p, d_part.p, tiles_max, d_prev5.p, ext_c);
         hipLaunchKernelGGL(lm_solve_kernel, dim3(nsweeps), dim3(64), 0, ctx->stream, d_sw.p, d_st.p, d_part.p,
                            tiles_max, it);
     }

@@ -625,7 +625,7 @@ __global__ __launch_bounds__(SBLOCK) void lm_rebuild_kernel(SegState *__restrict
     const int *voff = B.vin_off[type] + (long long)s * MAXVALID, *vocnt = B.vout_cnt[type] + (long long)s * MAXVALID;
     for (int c = threadIdx.x; c < LNUM; c += SBLOCK) kmap[c] = -1;
     __syncthreads();
-    if (threadIdx.x < G.nvalid) kmap[G.valid[threadIdx.x]] = (short)threadIdx.x;
+    if ((int)threadIdx.x < G.nvalid) kmap[G.valid[threadIdx.x]] = (short)threadIdx.x;
     __syncthreads();
     // exclusive scan of the final counts over the cubes: contiguous chunk per thread
     constexpr int PER = (LNUM + SBLOCK - 1) / SBLOCK;
@@ -727,7 +727,6 @@ struct LoamPipe {
     PipeDims dims{};
     PipeBufs B{};
     InArg<float> a_xyz;
-    InArg<double> a_stamps;
     DevBuf<float4> d_sharp, d_lsharp, d_flat, d_lflat;
     DevBuf<int> d_counts, d_ring_counts;
     std::vector<int> ring_cnt;      // nsw x 32: less-sharp / less-flat points per ring (from scanRegistration)
