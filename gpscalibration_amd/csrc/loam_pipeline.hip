@@ -24,6 +24,7 @@
 #include "loam_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 namespace gpscal {
@@ -895,9 +896,14 @@ struct LoamPipe {
 
     // One sweep per stream (sweep_idx[s] < 0: the stream idles).  Host outputs, nstream rows each:
     // published[s] (odometry emitted), mapped[s] (laserMapping ran), lo / lm / tm poses, track, iters.
+    double t_sec[6] = {0, 0, 0, 0, 0, 0};  // GPSCAL_LOAM_TIMING: host wall seconds per section of step()
     int step(const int *sweep_idx, int *published, int *mapped, float *lo, float *lm, float *tm, double *track,
              int *iters)
     {
+        typedef std::chrono::steady_clock clk;
+        auto t_now = [] { return clk::now(); };
+        auto t_add = [&](int k, clk::time_point a) { t_sec[k] += std::chrono::duration<double>(clk::now() - a).count(); };
+        auto t0 = t_now();
         hipStream_t q = ctx->stream;
         const int nseg = nstream;
         SegState *S = d_state.p;
@@ -965,6 +971,8 @@ struct LoamPipe {
         GPSCAL_HIP(ctx, hipMemsetAsync(d_step_tm.p, 0xff, sizeof(float) * 6 * nseg, q));
         GPSCAL_HIP(ctx, hipMemsetAsync(d_step_track.p, 0xff, sizeof(double) * 4 * nseg, q));
         GPSCAL_HIP(ctx, hipMemsetAsync(d_step_it.p, 0xff, sizeof(int) * nseg, q));
+        t_add(0, t0);
+        t0 = t_now();
         if (any_match) {
             // transform / transformSum live in SegState; the kernels take flat [nstream][6] arrays.  A
             // stream that idles or seeds has empty clouds here: its state passes through unchanged
@@ -976,6 +984,8 @@ struct LoamPipe {
             if (rc) return rc;
             hipLaunchKernelGGL(lo_state_kernel, dim3(div_up(nseg * 6, 64)), dim3(64), 0, q, S, nseg, d_tr.p, d_tr2.p, d_rows.p, 1);
         }
+        t_add(1, t0);
+        t0 = t_now();
         {
             const int gx = std::max(1, std::min(div_up(std::max(max_ls + max_lf, 1), 256), 64));
             hipLaunchKernelGGL(lo_post_kernel, dim3(gx, nseg), dim3(256), 0, q, d_post.p, S, d_lsharp.p, d_lflat.p,
@@ -1026,6 +1036,8 @@ struct LoamPipe {
                 sso += ns;
                 nmax = std::max(nmax, std::max(std::max(mc, ms), std::max(nc, ns)));
             }
+            t_add(2, t0);
+            t0 = t_now();
             GPSCAL_HIP(ctx, hipMemcpyAsync(d_pack.p, hpack.data(), sizeof(PackDesc) * nseg, hipMemcpyHostToDevice, q));
             hipLaunchKernelGGL(lm_pack_kernel, dim3(std::max(1, std::min(div_up(nmax, 256), 128)), nseg), dim3(256), 0, q,
                                d_pack.p, dims, B, d_cmap.p, d_smap.p, d_cstack.p, d_sstack.p);
@@ -1034,6 +1046,8 @@ struct LoamPipe {
             int rc = loam_mapping_device(ctx, nseg, hmap.data(), d_cstack.p, d_sstack.p, d_cmap.p, d_smap.p, cmoff.data(),
                                          smoff.data(), d_tr.p, d_tr2.p, d_iters.p, d_nsel.p);
             if (rc) return rc;
+            t_add(3, t0);
+            t0 = t_now();
             hipLaunchKernelGGL(lm_insert_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, S, dims, B, d_sizes.p, d_tr2.p,
                                d_iters.p, d_rows.p, d_step_lm.p, d_step_it.p, d_status.p);
             hipLaunchKernelGGL(lm_filter_kernel, dim3(MAXVALID, nseg * 2), dim3(SBLOCK), lds_keys, q, S, dims, B, d_status.p);
@@ -1041,12 +1055,15 @@ struct LoamPipe {
             hipLaunchKernelGGL(lm_flip_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, nseg);
             GPSCAL_HIP(ctx, hipGetLastError());
         }
+        t_add(4, t0);
+        t0 = t_now();
         if (lo) GPSCAL_HIP(ctx, hipMemcpyAsync(lo, d_step_lo.p, sizeof(float) * 6 * nseg, hipMemcpyDeviceToHost, q));
         if (lm) GPSCAL_HIP(ctx, hipMemcpyAsync(lm, d_step_lm.p, sizeof(float) * 6 * nseg, hipMemcpyDeviceToHost, q));
         if (tm) GPSCAL_HIP(ctx, hipMemcpyAsync(tm, d_step_tm.p, sizeof(float) * 6 * nseg, hipMemcpyDeviceToHost, q));
         if (iters) GPSCAL_HIP(ctx, hipMemcpyAsync(iters, d_step_it.p, sizeof(int) * nseg, hipMemcpyDeviceToHost, q));
         GPSCAL_HIP(ctx, hipMemcpyAsync(track, d_step_track.p, sizeof(double) * 4 * nseg, hipMemcpyDeviceToHost, q));
         GPSCAL_HIP(ctx, hipStreamSynchronize(q));
+        t_add(5, t0);
         for (int s = 0; s < nseg; ++s)
             if (sweep_idx[s] >= 0) {
                 ++local_t[s];
@@ -1057,6 +1074,9 @@ struct LoamPipe {
 
     int finish()
     {
+        if (getenv("GPSCAL_LOAM_TIMING"))
+            fprintf(stderr, "LoamPipe host seconds: setup %.3f | odometry %.3f | post+tm+prepare %.3f | pack+mapping %.3f | map update enqueue %.3f | final sync %.3f\n",
+                    t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4], t_sec[5]);
         int st = 0;
         GPSCAL_HIP(ctx, hipMemcpy(&st, d_status.p, sizeof(int), hipMemcpyDeviceToHost));
         if (st & 8) return fail(ctx, GPSCAL_ENOMEM, "LOAM chain: map pool capacity exceeded (raise corner_pool_cap / surf_pool_cap)");
