@@ -164,8 +164,12 @@ struct Reader {
                     std::vector<uint8_t> buf(usize);
                     if (!bunzip(d, buf)) return false;
                     if (!records(Span{buf.data(), buf.size()}, false)) return false;
+                } else if (comp == "lz4") {
+                    std::vector<uint8_t> buf(usize);
+                    if (!unlz4(d, buf)) return false;
+                    if (!records(Span{buf.data(), buf.size()}, false)) return false;
                 } else {
-                    return fail(("chunk compression '" + comp + "' is not supported (rosbag decompress the bag)").c_str());
+                    return fail(("chunk compression '" + comp + "' is not supported").c_str());
                 }
             }
             // 0x03 bag header, 0x04 index data, 0x06 chunk info: nothing to do for a sequential read
@@ -186,6 +190,47 @@ struct Reader {
         unsigned n = (unsigned)out.size();
         if (fn((char *)out.data(), &n, (char *)d.p, (unsigned)d.n, 0, 0) != 0 || n != out.size())
             return fail("bz2 chunk does not decompress to its declared size");
+        return true;
+    }
+
+    // roslz4 writes standard LZ4 frames; liblz4's frame API is bound at run time like libbz2
+    bool unlz4(Span d, std::vector<uint8_t> &out)
+    {
+        typedef size_t (*create_t)(void **, unsigned);
+        typedef size_t (*decomp_t)(void *, void *, size_t *, const void *, size_t *, const void *);
+        typedef size_t (*free_t)(void *);
+        typedef unsigned (*iserr_t)(size_t);
+        static create_t f_create = nullptr;
+        static decomp_t f_decomp = nullptr;
+        static free_t f_free = nullptr;
+        static iserr_t f_iserr = nullptr;
+        if (!f_create) {
+            void *h = dlopen("liblz4.so.1", RTLD_NOW);
+            if (h) {
+                f_create = (create_t)dlsym(h, "LZ4F_createDecompressionContext");
+                f_decomp = (decomp_t)dlsym(h, "LZ4F_decompress");
+                f_free = (free_t)dlsym(h, "LZ4F_freeDecompressionContext");
+                f_iserr = (iserr_t)dlsym(h, "LZ4F_isError");
+            }
+        }
+        if (!f_create || !f_decomp || !f_free || !f_iserr) return fail("lz4 chunk but liblz4 is not available");
+        void *ctx = nullptr;
+        if (f_iserr(f_create(&ctx, 100 /* LZ4F_VERSION */))) return fail("lz4: cannot create a decompression context");
+        size_t in_at = 0, out_at = 0;
+        bool ok = true;
+        while (in_at < d.n) {
+            size_t dst = out.size() - out_at, src = d.n - in_at;
+            const size_t rc = f_decomp(ctx, out.data() + out_at, &dst, d.p + in_at, &src, nullptr);
+            if (f_iserr(rc) || (dst == 0 && src == 0)) {
+                ok = false;
+                break;
+            }
+            in_at += src;
+            out_at += dst;
+            if (rc == 0) break;  // end of frame
+        }
+        f_free(ctx);
+        if (!ok || out_at != out.size()) return fail("lz4 chunk does not decompress to its declared size");
         return true;
     }
 

@@ -16,8 +16,8 @@ struct CloudSeries {
 };
 
 // Appends the topic's PointCloud2 messages of `path`, ordered by their record time, to `out`.
-// The topic matches with or without a leading slash.  Chunks may be uncompressed or bz2 (libbz2 is
-// loaded at run time when present); lz4 chunks are reported as unsupported.  Returns false and
+// The topic matches with or without a leading slash.  Chunks may be uncompressed, bz2 or lz4 (libbz2 /
+// liblz4 are loaded at run time when present).  Returns false and
 // fills `err` on any malformed record.
 bool read_bag_clouds(const std::string &path, const std::string &topic, CloudSeries &out, std::string &err);
 

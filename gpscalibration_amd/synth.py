@@ -456,7 +456,7 @@ def write_sweep_file(path, bags, stamps):
 def write_rosbag(path, sweeps, stamps, topic="/velodyne_points", chunk_msgs=6, with_ring=True, compression="none"):
     """Writes a rosbag V2.0 file holding one sensor_msgs/PointCloud2 message per sweep (Velodyne
     layout: x, y, z, intensity float32 + ring uint16, point_step 32), with connection, chunk, index
-    and chunk-info records, as `rosbag record` lays them out.  compression: "none" or "bz2"."""
+    and chunk-info records, as `rosbag record` lays them out.  compression: "none", "bz2" or "lz4"."""
     import bz2
     import struct
 
@@ -502,7 +502,21 @@ def write_rosbag(path, sweeps, stamps, topic="/velodyne_points", chunk_msgs=6, w
             index.append((stamps[k], len(body)))
             body += record([("op", b"\x02"), ("conn", struct.pack("<I", 0)), ("time", ros_time(stamps[k]))],
                            cloud_msg(k, stamps[k], sweeps[k]))
-        payload = bz2.compress(body) if compression == "bz2" else body
+        if compression == "bz2":
+            payload = bz2.compress(body)
+        elif compression == "lz4":  # roslz4 writes standard LZ4 frames
+            import ctypes as C
+            L = C.CDLL("liblz4.so.1")
+            L.LZ4F_compressFrameBound.restype = C.c_size_t
+            L.LZ4F_compressFrameBound.argtypes = [C.c_size_t, C.c_void_p]
+            L.LZ4F_compressFrame.restype = C.c_size_t
+            L.LZ4F_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+            cap = L.LZ4F_compressFrameBound(len(body), None)
+            dst = C.create_string_buffer(cap)
+            n = L.LZ4F_compressFrame(dst, cap, body, len(body), None)
+            payload = dst.raw[:n]
+        else:
+            payload = body
         chunk = record([("op", b"\x05"), ("compression", compression.encode()), ("size", struct.pack("<I", len(body)))], payload)
         idx = record([("op", b"\x04"), ("ver", struct.pack("<I", 1)), ("conn", struct.pack("<I", 0)),
                       ("count", struct.pack("<I", len(index)))],

@@ -101,13 +101,13 @@ def test_pose_allgather_gloo_world2(tmp_path):
 
 def test_rosbag_reader_round_trip(tmp_path):
     """host/rosbag_reader.cc (input_data.cpp:160-190, 305-313 without ROS): rosbag V2.0 records, chunked,
-    uncompressed and bz2, PointCloud2 decoding by field name -- against bags written by synth.write_rosbag."""
+    uncompressed, bz2 and lz4, PointCloud2 decoding by field name -- against bags written by synth.write_rosbag."""
     from gpscalibration_amd import pipeline, synth
     rng = np.random.default_rng(0)
     sweeps = [rng.normal(0, 20, (n, 3)).astype(np.float32) for n in (1000, 1, 0, 2500, 777, 64, 900)]
     sweeps[3][::97] = np.nan  # NaNs travel untouched (scanRegistration removes them, SR:265-266)
     stamps = 1494650700.0 + 0.1 * np.arange(len(sweeps)) + 0.000123
-    for comp in ("none", "bz2"):
+    for comp in ("none", "bz2", "lz4"):
         path = str(tmp_path / ("a_%s.bag" % comp))
         synth.write_rosbag(path, sweeps, stamps, topic="/velodyne_points", chunk_msgs=3, compression=comp)
         got, st = pipeline.read_bag(path, "velodyne_points")  # input_data queries the topic without the slash
