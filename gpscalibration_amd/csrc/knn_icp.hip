@@ -913,24 +913,19 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
         B->hpairs[b].n = sg.hpairs[b].m;
         maxn = std::max<long long>(maxn, sg.hpairs[b].m);
     }
-    // finite-point count per pair = cell_start at the end of the pair's cells
-    std::vector<unsigned> ends(np);
-    for (int b = 0; b < np; ++b) {
-        long long endcell = (b + 1 < np) ? sg.hpairs[b + 1].lv[0].cell_base : sg.total_cells;
-        GPSCAL_HIP(ctx, hipMemcpyAsync(&ends[b], sg.cell_start + endcell, sizeof(unsigned), hipMemcpyDeviceToHost,
-                                       ctx->stream));
-    }
+    // every source point must be finite: the grouped array then holds exactly sum(n) points (a pair's
+    // share can only shrink, so one total decides it)
+    unsigned grouped = 0;
+    GPSCAL_HIP(ctx, hipMemcpyAsync(&grouped, sg.cell_start + sg.total_cells, sizeof(unsigned), hipMemcpyDeviceToHost,
+                                   ctx->stream));
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned prev = 0;
-    for (int b = 0; b < np; ++b) {
-        unsigned finite = ends[b] - prev;
-        prev = ends[b];
-        if ((long long)finite != B->hpairs[b].n)
-            return fail(ctx, GPSCAL_EINVAL, "source cloud contains non-finite points (remove NaNs first, cf. scanRegistration.cpp:260-263)");
-    }
-    GPSCAL_HIP(ctx, B->src4.alloc((size_t)std::max<long long>(B->total_n, 1)));
-    GPSCAL_HIP(ctx, hipMemcpyAsync(B->src4.p, sg.sorted.p, sizeof(float4) * (size_t)B->total_n,
-                                   hipMemcpyDeviceToDevice, ctx->stream));
+    if ((long long)grouped != B->total_n)
+        return fail(ctx, GPSCAL_EINVAL, "source cloud contains non-finite points (remove NaNs first, cf. scanRegistration.cpp:260-263)");
+    // the grouped array IS src4 (one level): take the buffer over instead of copying it
+    std::swap(B->src4.p, sg.sorted.p);
+    std::swap(B->src4.n, sg.sorted.n);
+    std::swap(B->src4.pooled, sg.sorted.pooled);
+    std::swap(B->src4.pool_stream, sg.sorted.pool_stream);
     // block table
     const long long per_blk_target = (long long)ctx->prop.multiProcessorCount * 8 * BLOCK;
     (void)per_blk_target;
