@@ -988,9 +988,20 @@ extern "C" int gpscal_scan_batch_create(gpscal_ctx *ctx, int npairs, const float
     B->npairs = npairs;
     B->tgt = new GridSet;
     std::vector<long long> to(tgt_off, tgt_off + npairs + 1), so(src_off, src_off + npairs + 1);
+    auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t) {
+        if (getenv("GPSCAL_BUILD_TIMING")) {
+            auto n = std::chrono::steady_clock::now();
+            fprintf(stderr, "scan batch build: %s %.3f ms\n", what, 1e3 * std::chrono::duration<double>(n - t).count());
+            t = n;
+        }
+    };
+    auto tl = t0;
     int rc = build_grids(ctx, tgt_xyz, 12, to.data(), npairs, cell, MAX_LEVELS, *B->tgt);
+    lap("target grids", tl);
     if (!rc) rc = ensure_safe_radius(ctx, *B->tgt);
+    lap("neighbour lists + radii", tl);
     if (!rc) rc = batch_setup_sources(B, src_xyz, 12, so.data(), w);
+    lap("source grouping + state", tl);
     if (rc) {
         delete B;
         return rc;
