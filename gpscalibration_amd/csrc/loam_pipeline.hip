@@ -298,7 +298,8 @@ __global__ __launch_bounds__(SBLOCK) void lm_prepare_kernel(const PrepDesc *__re
     extern __shared__ unsigned long long dyn_lds[];
     __shared__ BlockShared S;
     __shared__ float tTobe[6];
-    __shared__ int s_shift[3], s_reset, s_valid[MAXVALID], s_nvalid, s_voff[2][MAXVALID + 1], s_cnt;
+    __shared__ int s_shift[3], s_reset, s_valid[MAXVALID], s_nvalid, s_voff[2][MAXVALID + 1], s_cnt, s_center[6];
+    __shared__ float s_pY[3];
     const int s = blockIdx.x;
     const PrepDesc D = descs[s];
     SegState &G = st[s];
@@ -342,31 +343,48 @@ __global__ __launch_bounds__(SBLOCK) void lm_prepare_kernel(const PrepDesc *__re
         while (cK < 3) { ++dK; ++cK; ++G.cenD; }
         while (cK >= LDp - 3) { --dK; --cK; --G.cenD; }
         s_shift[0] = dI; s_shift[1] = dJ; s_shift[2] = dK;
-        int nv = 0;
-        for (int i = cI - 2; i <= cI + 2; ++i)  // LM:653-712
-            for (int j = cJ - 2; j <= cJ + 2; ++j)
-                for (int k = cK - 2; k <= cK + 2; ++k) {
-                    if (!(i >= 0 && i < LW && j >= 0 && j < LH && k >= 0 && k < LDp)) continue;
-                    const float centerX = (float)(50.0 * (i - G.cenW)), centerY = (float)(50.0 * (j - G.cenH)),
-                                centerZ = (float)(50.0 * (k - G.cenD));
-                    bool inFOV = false;
-                    for (int ii = -1; ii <= 1; ii += 2)
-                        for (int jj = -1; jj <= 1; jj += 2)
-                            for (int kk = -1; kk <= 1; kk += 2) {
-                                const float cX = (float)((double)centerX + 25.0 * ii), cY = (float)((double)centerY + 25.0 * jj),
-                                            cZ = (float)((double)centerZ + 25.0 * kk);
-                                const float s1 = (tobe[3] - cX) * (tobe[3] - cX) + (tobe[4] - cY) * (tobe[4] - cY) +
-                                                 (tobe[5] - cZ) * (tobe[5] - cZ);
-                                const float s2 = (pY.x - cX) * (pY.x - cX) + (pY.y - cY) * (pY.y - cY) + (pY.z - cZ) * (pY.z - cZ);
-                                const float check1 = (float)(100.0 + (double)s1 - (double)s2 - 10.0 * sqrt(3.0) * (double)sqrtf(s1));
-                                const float check2 = (float)(100.0 + (double)s1 - (double)s2 + 10.0 * sqrt(3.0) * (double)sqrtf(s1));
-                                if (check1 < 0 && check2 > 0) inFOV = true;
-                            }
-                    if (inFOV) s_valid[nv++] = i + LW * j + LW * LH * k;
-                }
-        s_nvalid = nv;
-        G.nvalid = nv;
-        for (int k = 0; k < nv; ++k) G.valid[k] = s_valid[k];
+        s_center[0] = cI; s_center[1] = cJ; s_center[2] = cK;
+        s_center[3] = G.cenW; s_center[4] = G.cenH; s_center[5] = G.cenD;
+        s_pY[0] = pY.x; s_pY[1] = pY.y; s_pY[2] = pY.z;
+    }
+    __syncthreads();
+    // ---- the 5 x 5 x 5 cubes around the sensor that the field of view touches (LM:653-712): one lane
+    // per cube, kept in the reference's loop order (i, then j, then k) by an ordered compaction
+    {
+        const int c = threadIdx.x;
+        bool inFOV = false;
+        int cube = 0;
+        if (c < 125) {
+            const int i = s_center[0] - 2 + c / 25, j = s_center[1] - 2 + (c / 5) % 5, k = s_center[2] - 2 + c % 5;
+            if (i >= 0 && i < LW && j >= 0 && j < LH && k >= 0 && k < LDp) {
+                cube = i + LW * j + LW * LH * k;
+                const float centerX = (float)(50.0 * (i - s_center[3])), centerY = (float)(50.0 * (j - s_center[4])),
+                            centerZ = (float)(50.0 * (k - s_center[5]));
+                for (int ii = -1; ii <= 1; ii += 2)
+                    for (int jj = -1; jj <= 1; jj += 2)
+                        for (int kk = -1; kk <= 1; kk += 2) {
+                            const float cX = (float)((double)centerX + 25.0 * ii), cY = (float)((double)centerY + 25.0 * jj),
+                                        cZ = (float)((double)centerZ + 25.0 * kk);
+                            const float s1 = (tTobe[3] - cX) * (tTobe[3] - cX) + (tTobe[4] - cY) * (tTobe[4] - cY) +
+                                             (tTobe[5] - cZ) * (tTobe[5] - cZ);
+                            const float s2 = (s_pY[0] - cX) * (s_pY[0] - cX) + (s_pY[1] - cY) * (s_pY[1] - cY) +
+                                             (s_pY[2] - cZ) * (s_pY[2] - cZ);
+                            const float check1 = (float)(100.0 + (double)s1 - (double)s2 - 10.0 * sqrt(3.0) * (double)sqrtf(s1));
+                            const float check2 = (float)(100.0 + (double)s1 - (double)s2 + 10.0 * sqrt(3.0) * (double)sqrtf(s1));
+                            if (check1 < 0 && check2 > 0) inFOV = true;
+                        }
+            }
+        }
+        int tot;
+        const int r = block_rank(S, inFOV, tot);
+        if (inFOV) {
+            s_valid[r] = cube;
+            G.valid[r] = cube;
+        }
+        if (threadIdx.x == 0) {
+            s_nvalid = tot;
+            G.nvalid = tot;
+        }
     }
     __syncthreads();
     // ---- ring shift of both tables (register staged, in place)
