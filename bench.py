@@ -61,6 +61,36 @@ def cpu_baseline(points, iters, budget_s=20.0):
     }
 
 
+def cpu_baseline_all_cores(points, iters, budget_s=15.0):
+    """The same port on every host core the process may use: whole pairs are independent, so thread
+    t runs pairs t, t + C, ... (ctypes releases the GIL inside the C calls).  Reported next to the
+    single-thread figure, which is what the reference's one-thread-per-node design delivers."""
+    import threading
+    import _oracle as O
+    from gpscalibration_amd import synth
+    cores = max(1, min(len(os.sched_getaffinity(0)), 32))
+    pairs = [synth.scan_pair(points, p)[:2] for p in range(cores)]  # generated up front, outside the clock
+    done = [0] * cores
+    t_end = time.perf_counter() + budget_s
+
+    def work(t):
+        tgt, src = pairs[t]
+        while time.perf_counter() < t_end:
+            O.KdTree(tgt).icp_run(src, iters)
+            done[t] += iters
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    return {"value": sum(done) / dt, "unit": "ICP iterations/s", "cores": cores, "kind": "port",
+            "sample": "%d threads x whole %d-iteration runs of one %d-point pair each (kd-tree build included), %.1f s wall"
+                      % (cores, iters, points, dt)}
+
+
 def track_path_bench(tmpdir, total_poses=400000, long_len=1200, short_len=400, overlap=130, cpu_budget_s=10.0):
     """bag->KML half of the metric on a synthetic run (BASELINE configs[3]/[4] flavour: ~330 long and
     ~1480 short segments, 400 000 poses, 30 % GPS dropout): SLAM pose chains + GPRMC log -> calibrated
@@ -305,6 +335,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.iters)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(n, args.iters)
         if world == 1 and not args.no_loam:
             out["loam_chain"] = loam_chain_bench(ctx)
         if world == 1 and not args.no_track:
