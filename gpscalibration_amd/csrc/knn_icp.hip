@@ -1028,6 +1028,10 @@ extern "C" int gpscal_scan_batch_set_pose(gpscal_scan_batch *B, const double *T0
     }
     hipLaunchKernelGGL(pose_to_f32_kernel, dim3(div_up(np * 12, BLOCK)), dim3(BLOCK), 0, ctx->stream, B->pose64.p,
                        B->pose32.p, np);
+    // a new pose starts a new problem: the neighbours remembered from the previous run are forgotten, so
+    // that a run never profits from correspondences an earlier run computed
+    hipLaunchKernelGGL(fill_warm_kernel, dim3(div_up(std::max<long long>(B->total_n, 1), BLOCK)), dim3(BLOCK), 0,
+                       ctx->stream, B->warm_q.p, B->warm_r2.p, B->total_n);
     GPSCAL_HIP(ctx, hipGetLastError());
     return GPSCAL_OK;
 }
