@@ -208,16 +208,23 @@ __device__ __forceinline__ void scan_short(BT &B, bool act, const float4 *__rest
                                            float px, float py, float pz)
 {
     if (!act) return;
-    for (unsigned j = s; j < e; j += 4) {
+    unsigned j = s;
+    // full groups of four: no clamps, no per-candidate guards
+    for (; j + 4 <= e; j += 4) {
+        const float4 c0 = sorted[j], c1 = sorted[j + 1], c2 = sorted[j + 2], c3 = sorted[j + 3];
+        B.consider(sqdist(px, py, pz, c0.x, c0.y, c0.z), c0, j);
+        B.consider(sqdist(px, py, pz, c1.x, c1.y, c1.z), c1, j + 1);
+        B.consider(sqdist(px, py, pz, c2.x, c2.y, c2.z), c2, j + 2);
+        B.consider(sqdist(px, py, pz, c3.x, c3.y, c3.z), c3, j + 3);
+    }
+    if (j < e) {  // the last one to three, still fetched together
         const unsigned last = e - 1;
-        float4 c0 = sorted[j];
-        float4 c1 = sorted[min(j + 1, last)];
-        float4 c2 = sorted[min(j + 2, last)];
-        float4 c3 = sorted[min(j + 3, last)];
+        const float4 c0 = sorted[j];
+        const float4 c1 = sorted[min(j + 1, last)];
+        const float4 c2 = sorted[min(j + 2, last)];
         B.consider(sqdist(px, py, pz, c0.x, c0.y, c0.z), c0, j);
         if (j + 1 < e) B.consider(sqdist(px, py, pz, c1.x, c1.y, c1.z), c1, j + 1);
         if (j + 2 < e) B.consider(sqdist(px, py, pz, c2.x, c2.y, c2.z), c2, j + 2);
-        if (j + 3 < e) B.consider(sqdist(px, py, pz, c3.x, c3.y, c3.z), c3, j + 3);
     }
 }
 
