@@ -95,6 +95,7 @@ template <int K>
 struct Best {
     static constexpr bool COOP = false;  // k > 1: per-lane scanning only
     static constexpr bool WARM_START = true;
+    static constexpr bool BALL = false;
     float d[K];
     int i[K];
     __device__ __forceinline__ void init()
@@ -138,6 +139,7 @@ struct Best {
 struct BestQ {
     static constexpr bool COOP = true;  // long runs are scanned by the whole wave
     static constexpr bool WARM_START = true;  // worst() of a fresh record is a real candidate's distance
+    static constexpr bool BALL = true;        // worst() is the squared distance of the 1-NN so far: a ball radius
     static constexpr unsigned WARM = 0xffffffffu;
     static constexpr unsigned LIST = 0xfffffff0u;  // LIST + j: j-th entry of q0's neighbour list
     unsigned long long key;
@@ -167,6 +169,7 @@ struct BestQ {
 struct BestRing {
     static constexpr bool COOP = false;
     static constexpr bool WARM_START = false;  // the bound is a radius, not a candidate
+    static constexpr bool BALL = false;
     float d;
     int i;
     unsigned ord;
@@ -318,99 +321,189 @@ struct CellGeo {
     }
 };
 
-// Exact k-NN of (px,py,pz) in pair P, levels first_level.. fine -> coarse.  MUST be
-// called by all 64 lanes of a wave (act = false for lanes without a query): control
-// flow is wave-uniform so that long runs can be scanned cooperatively.
-// A level's 3x3x3 block of cells settles the query when the k-th best distance is
-// within the distance to the nearest face of the block that still has cells behind
-// it.  The coarsest level has <= 2 cells per axis, so it always settles.  Rows
-// (fixed y,z; x-1..x+1 contiguous in memory) and then single cells are skipped when
-// their nearest face is already farther than the k-th best, so a good starting
-// candidate (the previous iteration's neighbour) removes most of the memory traffic.
+// One level of the fine -> coarse search: the 3x3x3 block of cells around the query.  Rows
+// (fixed y,z; x-1..x+1 contiguous in memory) and then single cells are skipped when their
+// nearest face is already farther than the k-th best.  Wave-uniform.
 template <class BT>
+__device__ __forceinline__ void block3_level(const GridDesc &G, const CellGeo &C, const float4 *__restrict__ sorted,
+                                             const unsigned *__restrict__ cell_start, bool act, float px, float py,
+                                             float pz, BT &B)
+{
+    const float mg = G.margin;
+    const float bxl = fmaxf(C.fx0 - mg, 0.f), bxr = fmaxf(C.fx1 - mg, 0.f);
+    const bool has_l = C.cx > 0, has_r = C.cx + 1 < G.nx;
+    // face distances of the 3 x 3 rows: index 0 = own, 1 = lower, 2 = upper neighbour
+    const float by2[3] = {0.f, fmaxf(C.fy0 - mg, 0.f) * fmaxf(C.fy0 - mg, 0.f),
+                          fmaxf(C.fy1 - mg, 0.f) * fmaxf(C.fy1 - mg, 0.f)};
+    const float bz2[3] = {0.f, fmaxf(C.fz0 - mg, 0.f) * fmaxf(C.fz0 - mg, 0.f),
+                          fmaxf(C.fz1 - mg, 0.f) * fmaxf(C.fz1 - mg, 0.f)};
+    const bool yok[3] = {true, C.cy > 0, C.cy + 1 < G.ny};
+    const bool zok[3] = {true, C.cz > 0, C.cz + 1 < G.nz};
+    // rows this lane (lanemask) / some lane of the wave (wavemask) still has to look
+    // at; bit r = 3*kz + ky
+    unsigned wavemask = 0, lanemask = 0;
+    {
+        const float w0 = B.worst();
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const bool p = act && yok[r % 3] && zok[r / 3] && (by2[r % 3] + bz2[r / 3]) * 0.99999f <= w0;
+            if (p) lanemask |= 1u << r;
+            if (__ballot(p) != 0ull) wavemask |= 1u << r;
+        }
+    }
+    // cell_start[row-1 .. row+2] of row r: left | own | right cell boundaries.  The
+    // next row's quad is fetched while the current row's candidates are scanned.
+    auto load_quad = [&](int r) -> CellQuad {
+        CellQuad q = {0u, 0u, 0u, 0u};
+        if ((lanemask >> r) & 1u) {
+            const int kz = r / 3, ky = r - 3 * kz;
+            const int zz = C.cz + (kz == 0 ? 0 : (kz == 1 ? -1 : 1)), yy = C.cy + (ky == 0 ? 0 : (ky == 1 ? -1 : 1));
+            const long long row = G.cell_base + ((long long)zz * G.ny + yy) * G.nx + C.cx;
+            q = *reinterpret_cast<const CellQuad *>(cell_start + row - 1);
+        }
+        return q;
+    };
+    CellQuad nxt = {0u, 0u, 0u, 0u};
+    if (wavemask) nxt = load_quad(__builtin_ctz(wavemask));
+    while (wavemask) {  // wave-uniform
+        const int r = __builtin_ctz(wavemask);
+        wavemask &= wavemask - 1;
+        const CellQuad q = nxt;
+        if (wavemask) nxt = load_quad(__builtin_ctz(wavemask));
+        const int kz = r / 3, ky = r - 3 * kz;
+        const float rb2 = (ky == 0 ? 0.f : (ky == 1 ? by2[1] : by2[2])) + (kz == 0 ? 0.f : (kz == 1 ? bz2[1] : bz2[2]));
+        const bool pass = ((lanemask >> r) & 1u) && rb2 * 0.99999f <= B.worst();
+        if (__ballot(pass) == 0ull) continue;  // an earlier row tightened the bound
+        const unsigned c0 = has_l ? q.a : q.b, c1 = q.b, c2 = q.c, c3 = has_r ? q.d : q.c;
+        // left | own | right cells are one contiguous run: cells whose face is already
+        // within reach are scanned together with the own cell (one pass of loads instead
+        // of three dependent ones); a neighbour ruled out now stays ruled out, the bound
+        // only tightens.
+        const bool pl0 = pass && c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst();
+        const bool pr0 = pass && c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst();
+        scan_runs(B, pass, sorted, pl0 ? c0 : c1, pr0 ? c3 : c2, px, py, pz);
+    }
+}
+
+// One level of the ball search: every cell of a (2R+1)^3 block that the ball around the query
+// with the current k-th best distance as radius still reaches.  Slabs (fixed z) and rows (fixed
+// y,z) are visited nearest first and dropped when their face is out of reach; of a row only the
+// cells under the ball's x-extent are read -- they are one contiguous run of candidates between two
+// cell_start entries.  The caller guarantees R*h covers the radius.  Wave-uniform.
+template <class BT>
+__device__ __forceinline__ void ball_level(const GridDesc &G, const CellGeo &C, const float4 *__restrict__ sorted,
+                                           const unsigned *__restrict__ cell_start, bool act, float px, float py,
+                                           float pz, BT &B, int R)
+{
+    const float h = G.h, mg = G.margin;
+    for (int iz = 0; iz <= 2 * R; ++iz) {  // 0, -1, +1, -2, +2, ...
+        const int dz = (iz & 1) ? -((iz + 1) >> 1) : (iz >> 1);
+        const int zz = C.cz + dz;
+        float bz = 0.f;
+        if (dz != 0) bz = fmaxf((dz < 0 ? C.fz0 : C.fz1) + (float)(abs(dz) - 1) * h - mg, 0.f);
+        const float bz2 = bz * bz;
+        const bool inz = act && zz >= 0 && zz < G.nz;
+        if (__ballot(inz && bz2 * 0.99999f <= B.worst()) == 0ull) continue;
+        for (int iy = 0; iy <= 2 * R; ++iy) {
+            const int dy = (iy & 1) ? -((iy + 1) >> 1) : (iy >> 1);
+            const int yy = C.cy + dy;
+            float by = 0.f;
+            if (dy != 0) by = fmaxf((dy < 0 ? C.fy0 : C.fy1) + (float)(abs(dy) - 1) * h - mg, 0.f);
+            const float rb2 = (by * by + bz2) * 0.99999f;
+            const float w = B.worst();
+            const bool pass = inz && yy >= 0 && yy < G.ny && rb2 <= w;
+            if (__ballot(pass) == 0ull) continue;
+            unsigned s = 0u, e = 0u;
+            if (pass) {
+                // floor((x - o) / h) is monotone in x, and it is what sorted the points into cells:
+                // the cells of px -+ hw bracket every point within hw of px
+                const float hw = sqrtf(w - rb2) * 1.00001f + mg;
+                const int x0 = cell_coord(px - hw, G.ox, G.inv_h, G.nx), x1 = cell_coord(px + hw, G.ox, G.inv_h, G.nx);
+                const unsigned *row = cell_start + (G.cell_base + ((long long)zz * G.ny + yy) * G.nx);
+                s = row[x0];
+                e = row[x1 + 1];
+            }
+            scan_runs(B, pass, sorted, s, e, px, py, pz);
+        }
+    }
+}
+
+// Exact k-NN of (px,py,pz) in pair P.  MUST be called by all 64 lanes of a wave (act = false
+// for lanes without a query): control flow is wave-uniform so that long runs can be scanned
+// cooperatively.
+//
+// Fine -> coarse search (ball_r = 0): a level's 3x3x3 block of cells settles the query when the
+// k-th best distance is within the distance to the nearest face of the block that still has
+// cells behind it.  The coarsest level has <= 2 cells per axis, so it always settles.  A good
+// starting candidate (the previous iteration's neighbour) removes most of the memory traffic.
+//
+// Ball search (ball_r = R > 0, record types with BT::BALL): a query that holds a candidate at
+// distance r searches only the finest level whose (2R+1)^3 block covers the ball of radius r --
+// cells 2.5x .. R x 2.5x smaller than the level the 3x3x3 rule needs, i.e. fewer candidates under
+// the ball when the query is far from the surface the points sample.  Queries without a
+// candidate first climb the 3x3x3 blocks until they hold one.
+template <class BT, bool ALLOW_BALL = false>
 __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__restrict__ sorted,
                                           const unsigned *__restrict__ cell_start, bool act, float px, float py,
-                                          float pz, BT &B)
+                                          float pz, BT &B, int ball_r = 0)
 {
     if (!act) px = py = pz = 0.f;
-    // A lane that already holds a candidate skips the levels that cannot settle it:
-    // level l settles every query whose best is within h_l (the 3x3x3 block reaches
-    // at least one cell beyond the query's own), so the first such level is searched
-    // alone.  Without a candidate (first iteration) the search starts at level 0.
-    int start = 0;
+    const bool ballmode = ALLOW_BALL && BT::BALL && ball_r > 0;
+    // Pass 0, fine -> coarse.  A lane that already holds a candidate skips the levels that cannot
+    // settle it: level l settles every query whose best is within h_l (the 3x3x3 block reaches at
+    // least one cell beyond the query's own), so the first such level is searched alone.  Without a
+    // candidate (first iteration) the search starts at level 0.  In ball mode only lanes without a
+    // candidate take this pass, and they leave it as soon as they hold one.
+    // Pass 1 (ball mode): the one level chosen from the candidate's distance.
+    int lvl = 0;  // pass 0: first level to search; pass 1: the level to search
+    bool todo = act;
     {
         const float w0 = B.worst();
         if (BT::WARM_START && w0 < INFINITY) {
-            start = P.nlevels - 1;
+            if (ballmode) todo = false;
+            lvl = P.nlevels - 1;
             for (int l = P.nlevels - 2; l >= 0; --l) {
                 const float g = P.lv[l].h * 0.999f - P.lv[l].margin;
-                if (g > 0.f && w0 <= g * g) start = l;
+                if (g > 0.f && w0 <= g * g) lvl = l;
             }
         }
     }
-    bool todo = act;
-    for (int l = 0; l < P.nlevels; ++l) {
-        if (__ballot(todo) == 0ull) break;
-        const bool act = todo && l >= start;
-        if (__ballot(act) == 0ull) continue;
-        const GridDesc &G = P.lv[l];
-        CellGeo C;
-        C.set(G, px, py, pz);
-        const float mg = G.margin;
-        const float bxl = fmaxf(C.fx0 - mg, 0.f), bxr = fmaxf(C.fx1 - mg, 0.f);
-        const bool has_l = C.cx > 0, has_r = C.cx + 1 < G.nx;
-        // face distances of the 3 x 3 rows: index 0 = own, 1 = lower, 2 = upper neighbour
-        const float by2[3] = {0.f, fmaxf(C.fy0 - mg, 0.f) * fmaxf(C.fy0 - mg, 0.f),
-                              fmaxf(C.fy1 - mg, 0.f) * fmaxf(C.fy1 - mg, 0.f)};
-        const float bz2[3] = {0.f, fmaxf(C.fz0 - mg, 0.f) * fmaxf(C.fz0 - mg, 0.f),
-                              fmaxf(C.fz1 - mg, 0.f) * fmaxf(C.fz1 - mg, 0.f)};
-        const bool yok[3] = {true, C.cy > 0, C.cy + 1 < G.ny};
-        const bool zok[3] = {true, C.cz > 0, C.cz + 1 < G.nz};
-        // rows this lane (lanemask) / some lane of the wave (wavemask) still has to look
-        // at; bit r = 3*kz + ky
-        unsigned wavemask = 0, lanemask = 0;
-        {
+    bool ball = ballmode && act && !todo;
+    for (int pass = 0; pass < (ballmode ? 2 : 1); ++pass) {
+        if (pass == 1) {
+            if (__ballot(ball) == 0ull) break;
             const float w0 = B.worst();
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                const bool p = act && yok[r % 3] && zok[r / 3] && (by2[r % 3] + bz2[r / 3]) * 0.99999f <= w0;
-                if (p) lanemask |= 1u << r;
-                if (__ballot(p) != 0ull) wavemask |= 1u << r;
+            lvl = P.nlevels - 1;
+            for (int l = P.nlevels - 2; l >= 0; --l) {
+                const float g = (float)ball_r * P.lv[l].h * 0.999f - P.lv[l].margin;
+                if (g > 0.f && w0 <= g * g) lvl = l;
             }
         }
-        // cell_start[row-1 .. row+2] of row r: left | own | right cell boundaries.  The
-        // next row's quad is fetched while the current row's candidates are scanned.
-        auto load_quad = [&](int r) -> CellQuad {
-            CellQuad q = {0u, 0u, 0u, 0u};
-            if ((lanemask >> r) & 1u) {
-                const int kz = r / 3, ky = r - 3 * kz;
-                const int zz = C.cz + (kz == 0 ? 0 : (kz == 1 ? -1 : 1)), yy = C.cy + (ky == 0 ? 0 : (ky == 1 ? -1 : 1));
-                const long long row = G.cell_base + ((long long)zz * G.ny + yy) * G.nx + C.cx;
-                q = *reinterpret_cast<const CellQuad *>(cell_start + row - 1);
+        for (int l = 0; l < P.nlevels; ++l) {
+            const bool a = pass == 0 ? (todo && l >= lvl) : (ball && l == lvl);
+            if (pass == 0 && __ballot(todo) == 0ull) break;
+            if (__ballot(a) == 0ull) continue;
+            const GridDesc &G = P.lv[l];
+            CellGeo C;
+            C.set(G, px, py, pz);
+            // pass 1: a wave whose balls are all inside the 3x3x3 block takes the block search
+            // (prefetched rows); the top level has <= 2 cells per axis, so the block is the whole level
+            const float g1 = G.h * 0.999f - G.margin;
+            const bool far = pass == 1 && l != P.nlevels - 1 && !(g1 > 0.f && B.worst() <= g1 * g1);
+            if (!ALLOW_BALL || __ballot(a && far) == 0ull) {
+                block3_level(G, C, sorted, cell_start, a, px, py, pz, B);
+            } else {
+                ball_level(G, C, sorted, cell_start, a, px, py, pz, B, ball_r);
             }
-            return q;
-        };
-        CellQuad nxt = {0u, 0u, 0u, 0u};
-        if (wavemask) nxt = load_quad(__builtin_ctz(wavemask));
-        while (wavemask) {  // wave-uniform
-            const int r = __builtin_ctz(wavemask);
-            wavemask &= wavemask - 1;
-            const CellQuad q = nxt;
-            if (wavemask) nxt = load_quad(__builtin_ctz(wavemask));
-            const int kz = r / 3, ky = r - 3 * kz;
-            const float rb2 = (ky == 0 ? 0.f : (ky == 1 ? by2[1] : by2[2])) + (kz == 0 ? 0.f : (kz == 1 ? bz2[1] : bz2[2]));
-            const bool pass = ((lanemask >> r) & 1u) && rb2 * 0.99999f <= B.worst();
-            if (__ballot(pass) == 0ull) continue;  // an earlier row tightened the bound
-            const unsigned c0 = has_l ? q.a : q.b, c1 = q.b, c2 = q.c, c3 = has_r ? q.d : q.c;
-            // left | own | right cells are one contiguous run: cells whose face is already
-            // within reach are scanned together with the own cell (one pass of loads instead
-            // of three dependent ones); a neighbour ruled out now stays ruled out, the bound
-            // only tightens.
-            const bool pl0 = pass && c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst();
-            const bool pr0 = pass && c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst();
-            scan_runs(B, pass, sorted, pl0 ? c0 : c1, pr0 ? c3 : c2, px, py, pz);
+            if (pass == 0 && a) {
+                if (B.worst() <= C.settled_r2(G))
+                    todo = false;
+                else if (ballmode && B.worst() < INFINITY) {
+                    todo = false;
+                    ball = true;
+                }
+            }
         }
-        if (act && B.worst() <= C.settled_r2(G)) todo = false;
     }
 }
 

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
 // An LDS-staged variant of level 0 (workgroup box of cells copied to LDS) was built
 // and measured SLOWER than this pruned global path (the box holds ~3.3 points per
 // query against ~2.4 the query reads); see DESIGN.md.
-template <int QPT, bool WEIGHTED>
+template <int QPT, bool WEIGHTED, bool BALL>
 __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
     const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
     const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
             }
         }
         if (diag & 1) need = false;
-        knn_query(P, sorted, cell_start, need, px, py, pz, B);
+        knn_query<BestQ, BALL>(P, sorted, cell_start, need, px, py, pz, B, diag >> 8);
         if (!valid) continue;
         ok = ok && B.index() != 0x7fffffff;
         if (ok && B.pos != BestQ::WARM) {
@@ -803,6 +803,7 @@ struct gpscal_scan_batch {
     long long total_n = 0;
     bool weighted = false;
     int qpt = 1, nblk = 0, diag = 0;
+    int ball_r = 0;  // block radius of the ball search (0 = fine -> coarse 3x3x3 search)
     DevBuf<PairDesc> pairs;  // target descs + source fields
     std::vector<PairDesc> hpairs;
     DevBuf<float4> src4;
@@ -932,6 +933,21 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
     B->qpt = 1;  // measured: QPT 4 costs 117 VGPRs (4 waves/SIMD) and loses in the search-heavy early iterations
     if (const char *e = getenv("GPSCAL_QPT")) B->qpt = atoi(e) == 4 ? 4 : 1;  // tuning knobs
     if (const char *e = getenv("GPSCAL_DIAG")) B->diag = atoi(e);  // ablation (wrong results!)
+    {
+        // Dense clouds (level-0 cells under 0.25 m, i.e. ~1M points on a 100 m scene): a query that is still
+        // decimetres from the surface lies many cells away from it, and the 3x3x3 rule sends it to a level whose
+        // cells hold hundreds of points.  Measured (4 pairs x 1M points, 50 iterations): 942 -> 655 us per
+        // iteration with R = 4; neutral at 256k points (h0 0.34 m), 5 % slower at 64k (h0 0.68 m).
+        double hs = 0.0;
+        int cnt = 0;
+        for (int b = 0; b < np; ++b)
+            if (B->hpairs[b].m > 0) {
+                hs += B->hpairs[b].lv[0].h;
+                ++cnt;
+            }
+        if (cnt > 0 && hs / cnt < 0.25) B->ball_r = 4;
+    }
+    if (const char *e = getenv("GPSCAL_BALL_R")) B->ball_r = std::min(std::max(atoi(e), 0), 8);
     std::vector<int> bp, bf;
     for (int b = 0; b < np; ++b) {
         PairDesc &P = B->hpairs[b];
@@ -1041,15 +1057,17 @@ static void launch_step(gpscal_scan_batch *B, bool last)
     gpscal_ctx *ctx = B->ctx;
     GridSet &G = *B->tgt;
     if (B->nblk == 0) return;
-#define STEP(QPT, W)                                                                                         \
-    hipLaunchKernelGGL((icp_step_kernel<QPT, W>), dim3(B->nblk), dim3(BLOCK), 0, ctx->stream, B->pairs.p,     \
+#define STEP(QPT, W, BALL)                                                                                   \
+    hipLaunchKernelGGL((icp_step_kernel<QPT, W, BALL>), dim3(B->nblk), dim3(BLOCK), 0, ctx->stream, B->pairs.p, \
                        B->blk_pair.p, B->blk_first.p, B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p,  \
                        G.cell_start, B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p,        \
-                       B->partials.p, B->nblk, B->diag, last ? 1 : 0)
+                       B->partials.p, B->nblk, (B->diag & 0xff) | (B->ball_r << 8), last ? 1 : 0)
+    // the ball search costs the kernel a wave of occupancy: its own instantiation, chosen per batch
+    const bool ball = B->ball_r > 0;
     if (B->weighted) {
-        if (B->qpt == 4) STEP(4, true); else STEP(1, true);
+        if (B->qpt == 4) STEP(4, true, false); else if (ball) STEP(1, true, true); else STEP(1, true, false);
     } else {
-        if (B->qpt == 4) STEP(4, false); else STEP(1, false);
+        if (B->qpt == 4) STEP(4, false, false); else if (ball) STEP(1, false, true); else STEP(1, false, false);
     }
 #undef STEP
 }

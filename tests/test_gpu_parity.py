@@ -231,6 +231,15 @@ def test_icp_largest_config_sizes(ctx, n):
     sel = np.random.default_rng(n).choice(n, 1500, replace=False)
     ridx, rsqd = O.knn_brute(tgt, O.transform_f32(T[0], src[sel]), 1)
     assert np.array_equal(idx[sel], ridx[:, 0]) and np.array_equal(sqd[sel], rsqd[:, 0])
+    # far from convergence (second iteration from the identity: queries decimetres off the surface, seeded
+    # by the first iteration's neighbours; at 1M points this is the ball search)
+    sb.set_pose(None)
+    T1, _, _ = sb.icp(1)
+    sb.set_pose(None)
+    sb.icp(2)
+    idx, sqd = sb.correspondences()
+    ridx, rsqd = O.knn_brute(tgt, O.transform_f32(T1[0], src[sel]), 1)
+    assert np.array_equal(idx[sel], ridx[:, 0]) and np.array_equal(sqd[sel], rsqd[:, 0])
     sb.close()
     index = ctx.knn_index(tgt)
     q = src[sel[:500]] + np.float32(0.3)
@@ -238,6 +247,42 @@ def test_icp_largest_config_sizes(ctx, n):
     ri, rd = O.knn_brute(tgt, q, 3)
     assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
     index.close()
+
+
+@pytest.mark.parametrize("R", [1, 2, 4])
+def test_icp_ball_search_is_the_same_search(ctx, monkeypatch, R):
+    """Dense clouds take the ball search (GPSCAL_BALL_R, chosen by the level-0 cell size); it must return
+    what the fine -> coarse block search returns.  Small cells (0.12 m) put the queries many cells from
+    the surface, the regime it is for; both the seedless first iteration and the seeded ones are compared
+    with brute force and with the block search."""
+    npairs, n = 3, 20000
+    tg, to, sr, so, _ = synth.scan_batch(npairs, n)
+    out = {}
+    for r in (0, R):
+        monkeypatch.setenv("GPSCAL_BALL_R", str(r))
+        sb = ctx.scan_batch(tg, to, sr, so, cell_size=0.12)
+        T1, _, _ = sb.icp(1)
+        i1, d1 = sb.correspondences()
+        sb.set_pose(None)
+        T3, e3, _ = sb.icp(3)
+        i3, d3 = sb.correspondences()
+        out[r] = (T1.copy(), i1, d1, T3.copy(), i3, d3, e3.copy())
+        if r:
+            for p in range(npairs):
+                a, b = so[p], so[p + 1]
+                ridx, rsqd = O.knn_brute(tg[to[p]:to[p + 1]], sr[a:b], 1)  # iteration 1: identity pose
+                assert np.array_equal(i1[a:b], ridx[:, 0]) and np.array_equal(d1[a:b], rsqd[:, 0])
+            sb.set_pose(None)
+            T2, _, _ = sb.icp(2)  # pose the third iteration searched with
+            for p in range(npairs):
+                a, b = so[p], so[p + 1]
+                ridx, rsqd = O.knn_brute(tg[to[p]:to[p + 1]], O.transform_f32(T2[p], sr[a:b]), 1)
+                assert np.array_equal(i3[a:b], ridx[:, 0]) and np.array_equal(d3[a:b], rsqd[:, 0])
+        sb.close()
+    for k in (1, 2, 4, 5):
+        assert np.array_equal(out[0][k], out[R][k])
+    # two builds group the source points in a different order: the sums agree to rounding
+    assert np.abs(out[0][3] - out[R][3]).max() < 1e-12 and np.abs(out[0][6] - out[R][6]).max() < 1e-12
 
 
 # -------------------------------------------------------------------- track
