@@ -2,7 +2,7 @@
 results must be bit-identical, prints the per-iteration kernel times."""
 import os
 import sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.environ.get("AB_ROOT", "/root/repo"))
 import numpy as np
 import torch
 from gpscalibration_amd import Context, synth
