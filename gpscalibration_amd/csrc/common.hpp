@@ -57,13 +57,20 @@ inline bool is_device_ptr(const void *ptr)
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
-// GPSCAL_POISON=1 fills every fresh device allocation with 0xAB: a result that changes under it
-// reads memory nobody wrote (debug aid)
-inline bool poison()
+// GPSCAL_POISON=<byte> fills every fresh device allocation with that byte (1 = 0xAB): a result that
+// changes under it, or between two byte values, reads memory nobody wrote (debug aid).  0x41 makes stale
+// floats 12.08 -- a plausible coordinate -- and 0xAB -1.2e-12.
+inline int poison_byte()
 {
-    static const bool on = getenv("GPSCAL_POISON") != nullptr;
-    return on;
+    static const int v = [] {
+        const char *e = getenv("GPSCAL_POISON");
+        if (!e) return -1;
+        const long b = strtol(e, nullptr, 0);
+        return b == 1 ? 0xAB : (int)(b & 0xff);
+    }();
+    return v;
 }
+inline bool poison() { return poison_byte() >= 0; }
 
 template <class T>
 struct DevBuf {
@@ -93,7 +100,11 @@ struct DevBuf {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
         if (e == hipSuccess) {
             n = count;
-            if (poison()) (void)hipMemset(p, 0xAB, count * sizeof(T));
+            if (poison()) {
+                // the library's streams do not wait for the null stream: finish the fill before anyone writes
+                (void)hipMemset(p, poison_byte(), count * sizeof(T));
+                (void)hipDeviceSynchronize();
+            }
         }
         return e;
     }
@@ -108,7 +119,7 @@ struct DevBuf {
         hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&p), count * sizeof(T), stream);
         if (e == hipSuccess) {
             n = count;
-            if (poison()) (void)hipMemsetAsync(p, 0xAB, count * sizeof(T), stream);
+            if (poison()) (void)hipMemsetAsync(p, poison_byte(), count * sizeof(T), stream);
         } else
             pooled = false;
         return e;
