@@ -600,6 +600,64 @@ __global__ void gather_weights_kernel(const PairDesc *__restrict__ pairs, const 
     }
 }
 
+// Puts the points of every cell of a one-level grouping into original-index order.  The counting sort hands
+// out the slots of a cell with integer atomics, so the order inside a cell would otherwise differ from build
+// to build -- and with it the order in which the step kernel adds the float64 sums.  One lane per cell
+// (insertion sort, runs of <= 64); a wave takes the runs of 65..512 together (rank of every element, then one
+// scatter); longer runs (more than 512 points in one cell: degenerate input) stay as they are.
+__global__ __launch_bounds__(BLOCK) void order_runs_kernel(float4 *__restrict__ sorted,
+                                                            const unsigned *__restrict__ cell_start, long long ncells)
+{
+    const long long c = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    unsigned s = 0, n = 0;
+    if (c < ncells) {
+        s = cell_start[c];
+        n = cell_start[c + 1] - s;
+    }
+    if (n >= 2 && n <= 64) {
+        for (unsigned a = 1; a < n; ++a) {
+            const float4 key = sorted[s + a];
+            const int ki = __float_as_int(key.w);
+            unsigned b = a;
+            while (b > 0) {
+                const float4 prev = sorted[s + b - 1];
+                if (__float_as_int(prev.w) <= ki) break;
+                sorted[s + b] = prev;
+                --b;
+            }
+            sorted[s + b] = key;
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned long long m = __ballot(n > 64 && n <= 512);
+    while (m) {  // wave-uniform
+        const int owner = __builtin_ctzll(m);
+        m &= m - 1;
+        const unsigned ss = __builtin_amdgcn_readlane(s, owner), nn = __builtin_amdgcn_readlane(n, owner);
+        float4 el[8];
+        unsigned rk[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const unsigned i = lane + 64 * t;
+            el[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rk[t] = 0;
+            if (i < nn) el[t] = sorted[ss + i];
+        }
+        for (unsigned j = 0; j < nn; ++j) {
+            const int oj = __float_as_int(sorted[ss + j].w);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) rk[t] += oj < __float_as_int(el[t].w) ? 1u : 0u;
+        }
+        // every rank is known before the first element moves (one wave, program order)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const unsigned i = lane + 64 * t;
+            if (i < nn) sorted[ss + rk[t]] = el[t];
+        }
+    }
+}
+
 // ------------------------------------------------------------- host side
 
 
@@ -914,6 +972,11 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
         B->hpairs[b].n = sg.hpairs[b].m;
         maxn = std::max<long long>(maxn, sg.hpairs[b].m);
     }
+    // original-index order inside every cell: the grouping, and so the order of the sums, is the same in
+    // every build
+    if (sg.total_cells > 0)
+        hipLaunchKernelGGL(order_runs_kernel, dim3(div_up(sg.total_cells, BLOCK)), dim3(BLOCK), 0, ctx->stream,
+                           sg.sorted.p, sg.cell_start, sg.total_cells);
     // every source point must be finite: the grouped array then holds exactly sum(n) points (a pair's
     // share can only shrink, so one total decides it)
     unsigned grouped = 0;

@@ -1096,7 +1096,9 @@ struct LoamPipe {
             fprintf(stderr, "LoamPipe host seconds: setup %.3f | odometry %.3f | post+tm+prepare %.3f | pack+mapping %.3f | map update enqueue %.3f | final sync %.3f\n",
                     t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4], t_sec[5]);
         int st = 0;
-        GPSCAL_HIP(ctx, hipMemcpy(&st, d_status.p, sizeof(int), hipMemcpyDeviceToHost));
+        // on the library's stream: a null-stream copy would not wait for it (the stream is non-blocking)
+        GPSCAL_HIP(ctx, hipMemcpyAsync(&st, d_status.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (st & 8) return fail(ctx, GPSCAL_ENOMEM, "LOAM chain: map pool capacity exceeded (raise corner_pool_cap / surf_pool_cap)");
         if (st & 4) return fail(ctx, GPSCAL_ERANGE, "LOAM chain: internal scratch capacity exceeded");
         return GPSCAL_OK;

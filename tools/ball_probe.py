@@ -28,9 +28,7 @@ for npairs, n, iters in cases:
         if ref is None:
             ref = out
         else:
-            # the source grouping (atomic counting sort) changes the summation order between two builds:
-            # correspondences are exact, the pose agrees to rounding
-            ok = np.array_equal(ref[2], out[2]) and np.array_equal(ref[3], out[3]) and np.abs(ref[0] - out[0]).max() < 1e-9
+            ok = all(np.array_equal(a, b) for a, b in zip(ref, out))
             same = "same" if ok else "DIFFERENT"
         print(f"{npairs}x{n} R={R}: sum {ms.sum()*1e3:9.0f} us mean {ms.mean()*1e3:7.1f} us  {same}  first: "
               + " ".join(f"{v*1e3:.0f}" for v in ms[:int(os.environ.get("PROBE_NSHOW", "12"))]), flush=True)
