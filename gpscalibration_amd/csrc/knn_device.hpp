@@ -77,6 +77,12 @@ __device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n)
     return min(max(c, 0), n - 1);
 }
 
+// Cells of one level, in the numbering cell_of uses (a tiled level rounds x and y up to whole 8x8 tiles).
+__host__ __device__ __forceinline__ long long grid_cells(const GridDesc &G)
+{
+    return G.tile ? (long long)G.nz * ((G.ny + 7) / 8) * ((G.nx + 7) / 8) * 64 : (long long)G.nx * G.ny * G.nz;
+}
+
 __device__ __forceinline__ long long cell_of(const GridDesc &G, float x, float y, float z)
 {
     int cx = cell_coord(x, G.ox, G.inv_h, G.nx);

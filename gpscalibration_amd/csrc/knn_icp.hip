@@ -106,7 +106,9 @@ __global__ __launch_bounds__(BLOCK) void grid_count_kernel(const PairDesc *__res
     const int lc = P.coarse_from;  // levels lc.. are aggregated in LDS
     const long long co_base = lc < P.nlevels ? P.lv[lc].cell_base : 0;
     const GridDesc &Gt = P.lv[P.nlevels - 1];
-    const int nco = lc < P.nlevels ? (int)(Gt.cell_base + (long long)Gt.nx * Gt.ny * Gt.nz - co_base) : 0;
+    // (grid_cells, not nx*ny*nz: a tiled level -- the source grouping -- numbers whole 8x8 tiles; with the
+    // plain product a small tiled cloud left LDS bins unzeroed and unflushed: lost points and wild ranks)
+    const int nco = lc < P.nlevels ? (int)(Gt.cell_base + grid_cells(Gt) - co_base) : 0;
     for (int t = threadIdx.x; t < nco; t += BLOCK) hist[t] = 0u;
     __syncthreads();
     unsigned rl[GC_PT][MAX_LEVELS];
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
     const PairDesc &P = pairs[b];
     // level-0 block of this pair = positions [first0, end0)
     const unsigned first0 = cell_start[P.lv[0].cell_base];
-    const unsigned end0 = cell_start[P.lv[0].cell_base + (long long)P.lv[0].nx * P.lv[0].ny * P.lv[0].nz];
+    const unsigned end0 = cell_start[P.lv[0].cell_base + grid_cells(P.lv[0])];
     for (unsigned j0 = first0 + blockIdx.x * BLOCK; j0 < end0; j0 += gridDim.x * BLOCK) {
         const unsigned j = j0 + threadIdx.x;
         const bool act = j < end0;
@@ -780,7 +782,7 @@ int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long long *o
             P.coarse_from = P.nlevels;
             for (int l = P.nlevels - 1; l >= 0; --l) {
                 const GridDesc &G = P.lv[l];
-                acc += G.tile ? (long long)G.nz * ((G.ny + 7) / 8) * ((G.nx + 7) / 8) * 64 : (long long)G.nx * G.ny * G.nz;
+                acc += grid_cells(G);
                 if (acc > CO_MAX) break;
                 P.coarse_from = l;
             }
@@ -788,7 +790,7 @@ int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long long *o
         for (int l = 0; l < P.nlevels; ++l) {
             P.lv[l].cell_base = cells;
             const GridDesc &G = P.lv[l];
-            cells += G.tile ? (long long)G.nz * ((G.ny + 7) / 8) * ((G.nx + 7) / 8) * 64 : (long long)G.nx * G.ny * G.nz;
+            cells += grid_cells(G);
             sorted_total += P.m;
         }
     }

@@ -285,6 +285,61 @@ def test_icp_ball_search_is_the_same_search(ctx, monkeypatch, R):
     assert np.array_equal(out[0][3], out[R][3]) and np.array_equal(out[0][6], out[R][6])
 
 
+def test_icp_small_source_clouds_match_oracle(ctx):
+    """Sources of 1 .. 1000 points (the source grouping of a small cloud is one 8x8 tile per layer, counted in
+    LDS: a path the large benchmarks never take) against the oracle's ICP."""
+    tgt, src, _ = synth.scan_pair(3000, 4)
+    sizes = [1, 5, 33, 64, 65, 257, 1000]
+    tg = np.concatenate([tgt] * len(sizes)).astype(np.float32)
+    to = (np.arange(len(sizes) + 1) * len(tgt)).astype(np.int64)
+    srcs = [src[7 * k:7 * k + n] for k, n in enumerate(sizes)]
+    sr = np.concatenate(srcs).astype(np.float32)
+    so = np.cumsum([0] + sizes).astype(np.int64)
+    sb = ctx.scan_batch(tg, to, sr, so)
+    T, err, _ = sb.icp(3)
+    idx, sqd = sb.correspondences()
+    kd = O.KdTree(tgt)
+    for p, n in enumerate(sizes):
+        if n >= 3:
+            T_ref, hist = kd.icp_run(srcs[p], 3)
+            assert np.abs(T[p] - T_ref).max() < 1e-6 and np.abs(err[p] - hist).max() < 1e-6, n
+    # correspondences of the third iteration of the largest cloud against brute force
+    sb.set_pose(None)
+    T2, _, _ = sb.icp(2)
+    ridx, rsqd = O.knn_brute(tgt, O.transform_f32(T2[-1], srcs[-1]), 1)
+    assert np.array_equal(idx[so[-2]:], ridx[:, 0]) and np.array_equal(sqd[so[-2]:], rsqd[:, 0])
+    sb.close()
+
+
+def test_icp_ball_search_on_tiny_and_degenerate_targets(ctx, monkeypatch):
+    """Forced ball search where the level ladder is degenerate: targets of 1, 2 and 7 points, a target of
+    coincident points, a source far outside the target's box."""
+    monkeypatch.setenv("GPSCAL_BALL_R", "3")
+    rng = np.random.default_rng(11)
+    tgts = [rng.normal(0, 1, (1, 3)), rng.normal(0, 1, (2, 3)), rng.normal(0, 1, (7, 3)),
+            np.repeat(rng.normal(0, 1, (1, 3)), 50, axis=0), rng.normal(0, 0.5, (300, 3))]
+    srcs = [rng.normal(0, 2, (40, 3)), rng.normal(0, 2, (40, 3)), rng.normal(0, 2, (64, 3)),
+            rng.normal(0, 2, (70, 3)), rng.normal(0, 0.5, (200, 3)) + 40.0]
+    tg = np.concatenate(tgts).astype(np.float32)
+    sr = np.concatenate(srcs).astype(np.float32)
+    to = np.cumsum([0] + [len(t) for t in tgts]).astype(np.int64)
+    so = np.cumsum([0] + [len(t) for t in srcs]).astype(np.int64)
+    sb = ctx.scan_batch(tg, to, sr, so)
+    for iters in (1, 2):  # without and with remembered neighbours
+        sb.set_pose(None)
+        Tprev = np.tile(np.eye(4), (len(tgts), 1, 1))
+        if iters == 2:
+            Tprev, _, _ = sb.icp(1)
+            sb.set_pose(None)
+        sb.icp(iters)
+        idx, sqd = sb.correspondences()
+        for p in range(len(tgts)):
+            a, b = so[p], so[p + 1]
+            ridx, rsqd = O.knn_brute(tg[to[p]:to[p + 1]], O.transform_f32(Tprev[p], sr[a:b]), 1)
+            assert np.array_equal(idx[a:b], ridx[:, 0]) and np.array_equal(sqd[a:b], rsqd[:, 0]), (iters, p)
+    sb.close()
+
+
 def test_icp_two_builds_are_bit_identical(ctx):
     """The counting sort that groups the source points takes slots with atomics; order_runs_kernel then puts
     every cell into original-index order, so two builds add the float64 sums in the same order.  The cloud has a
