@@ -285,6 +285,66 @@ def test_icp_ball_search_is_the_same_search(ctx, monkeypatch, R):
     assert np.array_equal(out[0][3], out[R][3]) and np.array_equal(out[0][6], out[R][6])
 
 
+def _odd_cloud(rng, kind, n):
+    p = rng.normal(0, 3, (n, 3))
+    if kind == "plane":
+        p[:, 2] = 1.5
+    elif kind == "line":
+        p[:, 1] = -2.0
+        p[:, 2] = 0.25
+    elif kind == "point":
+        p[:] = rng.normal(0, 3, (1, 3))
+    elif kind == "outlier":
+        p[0] = [1.0e4, -2.0e4, 3.0e3]
+    elif kind == "offset":
+        p += [2.0e5, 1.0e5, 50.0]
+    elif kind == "dupes":
+        p[n // 2:] = p[: n - n // 2]
+    elif kind == "lattice":
+        p = np.round(p * 2) / 2  # many exact ties in distance
+    return p.astype(np.float32)
+
+
+@pytest.mark.parametrize("ball", [None, "2"])
+def test_knn_and_icp_odd_geometry_vs_brute_force(ctx, monkeypatch, ball):
+    """Degenerate bounding boxes (planes, lines, one point), far outliers, large offsets, duplicates and a
+    lattice full of distance ties, at small random sizes: k-NN and two ICP iterations against brute force."""
+    if ball:
+        monkeypatch.setenv("GPSCAL_BALL_R", ball)
+    rng = np.random.default_rng(2024)
+    kinds = ["plane", "line", "point", "outlier", "offset", "dupes", "lattice", "blob"]
+    tgts, srcs = [], []
+    for kind in kinds:
+        m, n = int(rng.integers(1, 900)), int(rng.integers(1, 700))
+        t = _odd_cloud(rng, kind, m)
+        s = _odd_cloud(rng, rng.choice(kinds), n) if kind != "offset" else (t[rng.integers(0, m, n)] + rng.normal(0, 0.3, (n, 3))).astype(np.float32)
+        tgts.append(t)
+        srcs.append(s)
+        ix = ctx.knn_index(t)
+        for k in (1, 3):
+            gi, gd = ix.search(s, k)
+            ri, rd = O.knn_brute(t, s, k)
+            assert np.array_equal(gi, ri) and np.array_equal(gd, rd), (kind, k)
+        ix.close()
+    tg, sr = np.concatenate(tgts), np.concatenate(srcs)
+    to = np.cumsum([0] + [len(t) for t in tgts]).astype(np.int64)
+    so = np.cumsum([0] + [len(t) for t in srcs]).astype(np.int64)
+    sb = ctx.scan_batch(tg, to, sr, so)
+    T1, _, _ = sb.icp(1)
+    i1, d1 = sb.correspondences()
+    sb.set_pose(None)
+    sb.icp(2)
+    i2, d2 = sb.correspondences()
+    for p, kind in enumerate(kinds):
+        a, b = so[p], so[p + 1]
+        ri, rd = O.knn_brute(tgts[p], srcs[p], 1)
+        assert np.array_equal(i1[a:b], ri[:, 0]) and np.array_equal(d1[a:b], rd[:, 0]), kind
+        assert np.isfinite(T1[p]).all(), kind
+        ri, rd = O.knn_brute(tgts[p], O.transform_f32(T1[p], srcs[p]), 1)
+        assert np.array_equal(i2[a:b], ri[:, 0]) and np.array_equal(d2[a:b], rd[:, 0]), kind
+    sb.close()
+
+
 def test_icp_small_source_clouds_match_oracle(ctx):
     """Sources of 1 .. 1000 points (the source grouping of a small cloud is one 8x8 tile per layer, counted in
     LDS: a path the large benchmarks never take) against the oracle's ICP."""

@@ -83,3 +83,11 @@ def test_voxel_grid_matches_oracle(ctx, raw):
             assert rc == 0
             assert g.shape == ref.shape and np.array_equal(g, ref)
     assert len(got[1]) < len(clouds[1]) // 3
+    # a single point, and leaves larger than the cloud (a voxel boundary still runs through the origin)
+    rng = np.random.default_rng(2)
+    odd = [rng.normal(0, 1, (1, 4)).astype(np.float32), rng.normal(0, 5, (5000, 4)).astype(np.float32)]
+    for leaf in (50.0, 1e6):
+        got = ctx.voxel_grid(odd, leaf)
+        for c, g in zip(odd, got):
+            ref, rc = O.voxel_grid(c, leaf)
+            assert rc == 0 and g.shape == ref.shape and np.array_equal(g, ref)
