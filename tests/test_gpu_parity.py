@@ -345,6 +345,30 @@ def test_knn_and_icp_odd_geometry_vs_brute_force(ctx, monkeypatch, ball):
     sb.close()
 
 
+def test_knn_volume_filling_cloud_with_millions_of_cells(ctx):
+    """Not lidar-like, but the ABI must survive it: 200 000 points filling a 500 m cube (level 0 gets ~18 M
+    cells, most of them empty; the scan over the cell counters runs three levels deep), explicit tiny cells
+    that hit the 2^25-cell cap, and strided / device-resident inputs."""
+    rng = np.random.default_rng(8)
+    t = rng.uniform(-250, 250, (200000, 3)).astype(np.float32)
+    q = rng.uniform(-260, 260, (300, 3)).astype(np.float32)
+    ri, rd = O.knn_brute(t, q, 2)
+    for cell in (0.0, 0.05):
+        ix = ctx.knn_index(t, cell_size=cell)
+        gi, gd = ix.search(q, 2)
+        assert np.array_equal(gi, ri) and np.array_equal(gd, rd), cell
+        ix.close()
+    import torch
+    t32 = np.zeros((len(t), 8), dtype=np.float32)  # PointXYZI-like 32-byte records
+    t32[:, :3] = t
+    ix = ctx.knn_index(torch.from_numpy(t32).cuda(), stride_bytes=32)
+    gi, gd = ix.search(torch.from_numpy(q).cuda(), 2)
+    assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
+    T, hist = ix.icp_run(q, 3)
+    assert np.isfinite(T).all()
+    ix.close()
+
+
 def test_icp_small_source_clouds_match_oracle(ctx):
     """Sources of 1 .. 1000 points (the source grouping of a small cloud is one 8x8 tile per layer, counted in
     LDS: a path the large benchmarks never take) against the oracle's ICP."""
