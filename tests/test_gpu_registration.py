@@ -70,6 +70,22 @@ def test_scan_registration_missing_ring_and_tiny_inputs(ctx, raw):
         assert len(got[2][name]) == 0
 
 
+def test_scan_registration_maximum_sweeps_in_few_rings(ctx):
+    """59 000 points on one ring and on two rings (sectors of ~10 000 points: far beyond the LDS sort
+    window), and a structureless 60 000-point cloud: same feature clouds as the oracle."""
+    a = np.linspace(0, 2 * np.pi, 59000, endpoint=False)
+    one = np.stack([10 * np.cos(a) + 0.2 * np.sin(7 * a), 10 * np.sin(a), np.zeros_like(a)], 1).astype(np.float32)
+    two = one.copy()
+    two[::2, 2] = np.float32(10 * np.tan(np.deg2rad(7.0)))
+    rnd = np.random.default_rng(9).normal(0, 20, (60000, 3)).astype(np.float32)
+    sweeps = [one, two, rnd]
+    got = ctx.scan_registration(sweeps)
+    for b, sweep in enumerate(sweeps):
+        ref = O.sr_extract(sweep)
+        for name in ("full", "sharp", "less_sharp", "flat", "less_flat"):
+            _same_cloud(got[b][name], ref[name], (b, name))
+
+
 def test_voxel_grid_matches_oracle(ctx, raw):
     """pcl::VoxelGrid restated (LM:1044-1058 uses leaves 0.2 and 0.4): bit-exact, including a cloud
     larger than the LDS sort window and one with NaNs."""

@@ -203,6 +203,49 @@ def odometry_empty_feature_sets():
     c.loam_mapping([z], [z], [p], [p]); c.loam_mapping([p[:50]], [p[:80]], [z], [z])
 
 
+@case
+def sr_maximum_size_single_ring_and_random():
+    from gpscalibration_amd._lib import GpscalError
+    c = _ctx(); r = _rng()
+    a = np.linspace(0, 2 * np.pi, 59000, endpoint=False)
+    one_ring = np.stack([10 * np.cos(a), 10 * np.sin(a), np.zeros_like(a)], 1).astype(np.float32)
+    two_rings = one_ring.copy(); two_rings[::2, 2] = 10 * np.tan(np.deg2rad(7.0))
+    rnd = r.normal(0, 20, (60000, 3)).astype(np.float32)
+    for name, sw in (("one ring", one_ring), ("two rings", two_rings), ("random 60000", rnd), ("random 60001", np.concatenate([rnd, rnd[:1]]))):
+        try:
+            out = c.scan_registration([sw]); print("  %s: %s" % (name, {k: len(v) for k, v in out[0].items()}))
+        except GpscalError as e:
+            print("  %s -> error %s" % (name, e))
+
+
+@case
+def knn_k_out_of_range_is_an_error():
+    from gpscalibration_amd._lib import GpscalError
+    c = _ctx(); ix = c.knn_index(_rng().normal(0, 1, (100, 3)).astype(np.float32))
+    for k in (0, 9, -1):
+        try:
+            ix.search(np.zeros((4, 3), np.float32), k); raise SystemExit("k=%d accepted" % k)
+        except (GpscalError, ValueError) as e:
+            print("  k=%d -> %s" % (k, str(e)[:80]))
+
+
+@case
+def track_long_and_many_segments():
+    c = _ctx(); r = _rng()
+    n = 20000
+    s = np.cumsum(r.normal(0, 1, (n, 4)), 0); s[:, 3] = np.arange(n) * 0.1
+    e = s + r.normal(0, 0.5, (n, 4)); e[:, 3] = s[:, 3]
+    c.track_fit(s, e, np.ones(n)); c.long_segment(s, e)
+    off = np.arange(0, n + 1, 2).astype(np.int32)  # 10 000 segments of two poses
+    c.track_fit(s, e, np.ones(n), seg_offsets=off); c.long_segment(s, e, seg_offsets=off)
+
+
+@case
+def voxel_large_cloud_many_cells():
+    c = _ctx(); r = _rng()
+    out = c.voxel_grid([r.uniform(-200, 200, (300000, 4)).astype(np.float32)], 0.5); print("  kept", len(out[0]))
+
+
 if len(sys.argv) > 2 and sys.argv[1] == "--run":
     CASES[sys.argv[2]]()
     print("  done")
