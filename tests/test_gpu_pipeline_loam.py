@@ -66,6 +66,22 @@ def test_loam_run_two_segments_match_oracle(ctx):
     assert np.array_equal(got[0]["lm_iters"], ref_a["lm_iters"])
 
 
+def test_loam_run_degenerate_corridor(ctx):
+    """Two unbroken walls and no poles: motion along the corridor is unobservable (laserOdometry's
+    degeneracy projection, LO:987-1012, and near-singular 6x6 systems in laserMapping).  The chain must
+    still do what the restatement does -- including estimating almost no forward motion."""
+    L = 300.0
+    W = {"boxes": np.array([[-40.0, L + 40.0, 9.0, 15.0, 8.0], [-40.0, L + 40.0, -15.0, -9.0, 8.0],
+                            [-60.0, -45.0, -40.0, 40.0, 10.0], [L + 45.0, L + 60.0, -40.0, 40.0, 10.0]]),
+         "poles": np.zeros((0, 3))}
+    sw, st, truth = synth.drive(W, 20, seed=3, n_az=900)
+    got = ctx.loam_run([sw], [st])[0]
+    ref = O.loam_run(sw, st)
+    _check(got, ref, 20)
+    assert np.array_equal(got["lm_iters"], ref["lm_iters"])
+    assert abs(ref["tm_mapped"][-1][5]) < 1.0 < truth[-1][0]  # the corridor hides the 16 m the vehicle drove
+
+
 def test_loam_run_ring_shift(ctx):
     """A drive that starts 30 m from the street origin and covers 60 m crosses laserMapping's
     cube borders (50 m cubes, LM:489-495); the map pool is rebuilt through several cube populations."""
