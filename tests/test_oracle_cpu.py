@@ -30,12 +30,17 @@ def test_survey_kat_gps_to_enu_and_back(gps_log_bytes):
     assert len(lat) == 1002  # fixes within [(long)(t0-1), (long)(t1+1)]
     enu = O.gps_to_enu(lat, lon, t, slam)
     assert len(enu) == 1000
-    assert "%.6f" % enu[0, 0] == "3450164.856218"
-    assert "%.6f" % enu[0, 1] == "400633250.787481"
+    import json
+    with open(os.path.join(GOLDEN, "survey_known_answers.json")) as f:
+        kat = json.load(f)  # what the reference's own gps_process.cc printed (golden/README.md)
+    assert "%.6f" % enu[0, 0] == "%.6f" % kat["enu_first"][0] == "3450164.856218"
+    assert "%.6f" % enu[0, 1] == "%.6f" % kat["enu_first"][1] == "400633250.787481"
     ll, alt = O.local_to_wgs(np.c_[enu, np.ones(len(enu))])
-    assert "%.9f %.9f" % (ll[0, 0], ll[0, 1]) == "121.398330784 31.177944836"
+    assert "%.9f %.9f" % (ll[0, 0], ll[0, 1]) == "%.9f %.9f" % tuple(kat["wgs84_back_first"])
     text = O.kml(ll, alt, 0)
-    assert "121.398330784171,31.177944836485,10\n" in text
+    assert kat["kml_line_first"] + "\n" in text
+    w = O.weights_speed(np.c_[enu[:, :2], np.zeros(len(enu)), st])
+    assert w[-1] == kat["last_speed_weight"]
 
 
 def test_parse_shipped_log_shape(gps_log_bytes):
