@@ -184,3 +184,18 @@ def test_driver_gga_log_and_map_json_outputs(tmp_path):
         assert np.abs(num(outs[rc][0]) - num(ref0)).max() < 1e-9
         assert np.abs(num(outs[rc][1]) - num(ref1)).max() < 1e-9
     assert outs[1][0].startswith("<?xml") and len(_kml_coords(outs[1][0])) == len(gps)
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_uninitialised_device_memory():
+    """tools/poison_probe.py: the LOAM pipeline, an ICP batch, a k-NN search and scanRegistration in child
+    processes whose fresh device allocations are filled with 0x41 (stale floats read 12.08, a plausible
+    coordinate) and 0xff (NaN): every output must equal the unpoisoned run bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PROBE_TAGS="p41,pff")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "poison_probe.py")], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "False" not in out and "FAILED" not in out, out[-2000:]

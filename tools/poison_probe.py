@@ -36,6 +36,11 @@ def same(x, y):
 
 
 tags = {"none": None, "ab": "0xAB", "p41": "0x41", "p7f": "0x7f", "pff": "0xff"}
+if os.environ.get("PROBE_TAGS"):
+    tags = {t: v for t, v in tags.items() if t == "none" or t in os.environ["PROBE_TAGS"].split(",")}
+for t in tags:
+    if os.path.exists(tmp + "/%s.pkl" % t):
+        os.remove(tmp + "/%s.pkl" % t)
 for t, v in tags.items():
     env = dict(os.environ)
     env.pop("GPSCAL_POISON", None)
@@ -45,10 +50,10 @@ for t, v in tags.items():
     if r.returncode:
         print(t, "FAILED", r.stdout.decode()[-800:])
 R = {t: pickle.load(open(tmp + "/%s.pkl" % t, "rb")) for t in tags if os.path.exists(tmp + "/%s.pkl" % t)}
+bad = False
 for t in R:
     for k in R["none"]:
-        if k in ("T", "err"):  # two builds group the source differently: rounding-level agreement only
-            ok = np.abs(R[t][k] - R["none"][k]).max() < 1e-9
-        else:
-            ok = same(R[t][k], R["none"][k])
+        ok = same(R[t][k], R["none"][k])
         print(t, k, "same as unpoisoned:", ok, flush=True)
+        bad = bad or not ok
+sys.exit(1 if bad or len(R) != len(tags) else 0)
