@@ -53,8 +53,11 @@ int orc_knn_brute(const float *tgt, int m, const float *q, int n, int k,
         int cnt = 0;
         int32_t *ii = idx + (size_t)i * k;
         float *dd = sqd + (size_t)i * k;
-        for (int j = 0; j < m; ++j)
-            klist_insert(k, ii, dd, &cnt, j, orc_sqdist(q + 3 * i, tgt + 3 * j));
+        for (int j = 0; j < m; ++j) {
+            const float *c = tgt + 3 * (size_t)j;
+            if (!(isfinite(c[0]) && isfinite(c[1]) && isfinite(c[2]))) continue; /* never a neighbour */
+            klist_insert(k, ii, dd, &cnt, j, orc_sqdist(q + 3 * i, c));
+        }
         for (int r = cnt; r < k; ++r) {
             ii[r] = -1;
             dd[r] = INFINITY;
@@ -161,14 +164,21 @@ orc_kdtree *orc_kdtree_build(const float *tgt, int m)
     t->pts = tgt;
     t->m = m;
     t->perm = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
-    for (int i = 0; i < m; ++i) t->perm[i] = i;
+    /* non-finite points are never indexed nor returned (what setInputCloud's IndicesPtr of a cloud that went
+     * through removeNaNFromPointCloud amounts to, scanRegistration.cpp:260-263); a NaN would also send the
+     * median split below into an endless loop */
+    int mf = 0;
+    for (int i = 0; i < m; ++i)
+        if (isfinite(tgt[3 * (size_t)i]) && isfinite(tgt[3 * (size_t)i + 1]) && isfinite(tgt[3 * (size_t)i + 2]))
+            t->perm[mf++] = i;
+    t->m = m = mf;
     for (int d = 0; d < 3; ++d) {
         t->bbmin[d] = INFINITY;
         t->bbmax[d] = -INFINITY;
     }
     for (int i = 0; i < m; ++i)
         for (int d = 0; d < 3; ++d) {
-            float v = tgt[3 * (size_t)i + d];
+            float v = tgt[3 * (size_t)t->perm[i] + d];
             if (v < t->bbmin[d]) t->bbmin[d] = v;
             if (v > t->bbmax[d]) t->bbmax[d] = v;
         }

@@ -302,7 +302,17 @@ def _odd_cloud(rng, kind, n):
         p[n // 2:] = p[: n - n // 2]
     elif kind == "lattice":
         p = np.round(p * 2) / 2  # many exact ties in distance
+    elif kind == "nans":
+        p[::9, rng.integers(0, 3)] = np.nan  # target points that are never indexed nor returned
     return p.astype(np.float32)
+
+
+def _brute_finite(t, q, k):
+    """Brute force over the finite target points only (non-finite ones are never indexed nor returned by the
+    product; the oracle's brute force is not defined for them), indices mapped back to the full cloud."""
+    fin = np.flatnonzero(np.isfinite(t).all(axis=1))
+    ri, rd = O.knn_brute(t[fin], q, k)
+    return np.where(ri >= 0, fin[np.maximum(ri, 0)], -1).astype(np.int32), rd
 
 
 @pytest.mark.parametrize("ball", [None, "2"])
@@ -312,18 +322,19 @@ def test_knn_and_icp_odd_geometry_vs_brute_force(ctx, monkeypatch, ball):
     if ball:
         monkeypatch.setenv("GPSCAL_BALL_R", ball)
     rng = np.random.default_rng(2024)
-    kinds = ["plane", "line", "point", "outlier", "offset", "dupes", "lattice", "blob"]
+    kinds = ["plane", "line", "point", "outlier", "offset", "dupes", "lattice", "blob", "nans"]
+    src_kinds = [k for k in kinds if k != "nans"]  # a source must be finite
     tgts, srcs = [], []
     for kind in kinds:
         m, n = int(rng.integers(1, 900)), int(rng.integers(1, 700))
         t = _odd_cloud(rng, kind, m)
-        s = _odd_cloud(rng, rng.choice(kinds), n) if kind != "offset" else (t[rng.integers(0, m, n)] + rng.normal(0, 0.3, (n, 3))).astype(np.float32)
+        s = _odd_cloud(rng, rng.choice(src_kinds), n) if kind != "offset" else (t[rng.integers(0, m, n)] + rng.normal(0, 0.3, (n, 3))).astype(np.float32)
         tgts.append(t)
         srcs.append(s)
         ix = ctx.knn_index(t)
         for k in (1, 3):
             gi, gd = ix.search(s, k)
-            ri, rd = O.knn_brute(t, s, k)
+            ri, rd = _brute_finite(t, s, k)
             assert np.array_equal(gi, ri) and np.array_equal(gd, rd), (kind, k)
         ix.close()
     tg, sr = np.concatenate(tgts), np.concatenate(srcs)
@@ -337,10 +348,10 @@ def test_knn_and_icp_odd_geometry_vs_brute_force(ctx, monkeypatch, ball):
     i2, d2 = sb.correspondences()
     for p, kind in enumerate(kinds):
         a, b = so[p], so[p + 1]
-        ri, rd = O.knn_brute(tgts[p], srcs[p], 1)
+        ri, rd = _brute_finite(tgts[p], srcs[p], 1)
         assert np.array_equal(i1[a:b], ri[:, 0]) and np.array_equal(d1[a:b], rd[:, 0]), kind
         assert np.isfinite(T1[p]).all(), kind
-        ri, rd = O.knn_brute(tgts[p], O.transform_f32(T1[p], srcs[p]), 1)
+        ri, rd = _brute_finite(tgts[p], O.transform_f32(T1[p], srcs[p]), 1)
         assert np.array_equal(i2[a:b], ri[:, 0]) and np.array_equal(d2[a:b], rd[:, 0]), kind
     sb.close()
 
