@@ -63,6 +63,7 @@ extern "C" int gpscal_destroy(gpscal_ctx *ctx)
     if (ctx->comm) (void)gpscal_comm_destroy(ctx);
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
+        cache_trim(ctx->stream);  // the stream's cached temporaries go back to the driver
         (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;

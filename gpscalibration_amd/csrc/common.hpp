@@ -9,7 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/gpscal.h"
@@ -72,11 +75,122 @@ inline int poison_byte()
 }
 inline bool poison() { return poison_byte() >= 0; }
 
+// Per-call grid sets of the LOAM chain come from the stream's block cache (no device-wide sync on release).
+// GPSCAL_POOL_GRIDS=0 goes back to hipMalloc / hipFree (debugging aid).
+inline bool pool_grids()
+{
+    static const bool on = [] {
+        const char *e = getenv("GPSCAL_POOL_GRIDS");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return on;
+}
+
+
+// ---------------------------------------------------------------- per-stream block cache
+// Per-call temporaries come from a cache of hipMalloc'd blocks owned by the library, one cache per stream:
+// a block goes back to the cache of the stream its last user enqueued work on, and whoever takes it next
+// enqueues on that same stream -- in-order execution is all the ordering reuse needs, so neither taking nor
+// returning a block synchronises the device (hipMalloc / hipFree do).  This replaces hipMallocAsync /
+// hipFreeAsync: with ROCm 7.2's own runtime the stream-ordered pool made this library abort inside
+// gpscal_knn_build and return stale output buffers (the same binary is correct with plain allocations and
+// under the older runtime PyTorch bundles); round 1's "pooled grid sets are not reproducible" was the same thing.
+struct BlockCache {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;    // cached, by size
+    std::unordered_map<void *, size_t> handed_out;  // live blocks -> size
+    size_t cached_bytes = 0;
+    static size_t round_size(size_t bytes)
+    {
+        size_t s = 512;
+        if (bytes <= (1u << 20)) {
+            while (s < bytes) s <<= 1;
+            return s;
+        }
+        const size_t step = bytes < (64ull << 20) ? (1ull << 20) : (16ull << 20);
+        return (bytes + step - 1) / step * step;
+    }
+};
+inline std::mutex &cache_registry_mutex()
+{
+    static std::mutex *m = new std::mutex;  // leaked on purpose: no static-destruction order to worry about
+    return *m;
+}
+inline BlockCache &cache_of(hipStream_t stream)
+{
+    static auto *reg = new std::unordered_map<hipStream_t, BlockCache *>;
+    std::lock_guard<std::mutex> lk(cache_registry_mutex());
+    BlockCache *&c = (*reg)[stream];
+    if (!c) c = new BlockCache;
+    return *c;
+}
+// Frees every cached block of the stream (the caller has synchronised the stream).
+inline void cache_trim(hipStream_t stream, size_t keep_bytes = 0)
+{
+    BlockCache &C = cache_of(stream);
+    std::lock_guard<std::mutex> lk(C.mu);
+    while (C.cached_bytes > keep_bytes && !C.free_blocks.empty()) {
+        auto it = std::prev(C.free_blocks.end());  // largest first
+        (void)hipFree(it->second);
+        C.cached_bytes -= it->first;
+        C.free_blocks.erase(it);
+    }
+}
+inline hipError_t cache_alloc(void **out, size_t bytes, hipStream_t stream)
+{
+    BlockCache &C = cache_of(stream);
+    const size_t need = BlockCache::round_size(bytes);
+    {
+        std::lock_guard<std::mutex> lk(C.mu);
+        auto it = C.free_blocks.lower_bound(need);
+        if (it != C.free_blocks.end() && it->first <= need + need / 2) {  // close enough in size
+            *out = it->second;
+            C.cached_bytes -= it->first;
+            C.handed_out[*out] = it->first;
+            C.free_blocks.erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, need);
+    if (e != hipSuccess) {  // make room: drop what is cached (work using it may still be queued)
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(stream);
+        cache_trim(stream);
+        e = hipMalloc(out, need);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lk(C.mu);
+    C.handed_out[*out] = need;
+    return hipSuccess;
+}
+inline void cache_free(void *p, hipStream_t stream)
+{
+    constexpr size_t CACHE_CAP = 8ull << 30;  // cached (idle) bytes per stream before blocks go back to the driver
+    BlockCache &C = cache_of(stream);
+    bool trim = false;
+    {
+        std::lock_guard<std::mutex> lk(C.mu);
+        auto it = C.handed_out.find(p);
+        if (it == C.handed_out.end()) {  // not ours (should not happen): give it back the plain way
+            (void)hipFree(p);
+            return;
+        }
+        C.free_blocks.emplace(it->second, p);
+        C.cached_bytes += it->second;
+        C.handed_out.erase(it);
+        trim = C.cached_bytes > CACHE_CAP;
+    }
+    if (trim) {
+        (void)hipStreamSynchronize(stream);
+        cache_trim(stream, CACHE_CAP / 2);
+    }
+}
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
-    hipStream_t pool_stream = nullptr;  // set: stream-ordered allocation (hipMallocAsync pool)
+    hipStream_t pool_stream = nullptr;  // set: block of this stream's cache (see BlockCache)
     bool pooled = false;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
@@ -85,7 +199,7 @@ struct DevBuf {
     void release()
     {
         if (p) {
-            if (pooled) (void)hipFreeAsync(p, pool_stream);
+            if (pooled) cache_free(p, pool_stream);
             else (void)hipFree(p);
         }
         p = nullptr;
@@ -108,20 +222,22 @@ struct DevBuf {
         }
         return e;
     }
-    // Stream-ordered allocation from the device pool: for per-call temporaries.  Freed in
-    // stream order too, so no device-wide synchronisation (hipFree would add one).
+    // A block of the stream's cache: for per-call temporaries.  No device-wide synchronisation on either
+    // end (hipMalloc / hipFree have one); the buffer may only be used by work enqueued on `stream`.
     hipError_t alloc_async(size_t count, hipStream_t stream)
     {
         release();
         if (count == 0) count = 1;
-        pooled = true;
-        pool_stream = stream;
-        hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&p), count * sizeof(T), stream);
+        hipError_t e = cache_alloc(reinterpret_cast<void **>(&p), count * sizeof(T), stream);
         if (e == hipSuccess) {
+            pooled = true;
+            pool_stream = stream;
             n = count;
             if (poison()) (void)hipMemsetAsync(p, poison_byte(), count * sizeof(T), stream);
-        } else
+        } else {
+            p = nullptr;
             pooled = false;
+        }
         return e;
     }
 };

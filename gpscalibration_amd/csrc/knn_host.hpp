@@ -20,6 +20,7 @@ struct GridSet {
     DevBuf<unsigned> cell_start_buf;  // 4 pad + cells + 1 + 4 pad
     unsigned *cell_start = nullptr;
     long long total_cells = 0, total_sorted = 0;
+    bool pooled = false;  // per-call grid sets: stream-ordered allocations, no device-wide sync on release
 };
 
 // Builds the level ladders and the counting-sorted copies for npairs clouds

@@ -731,7 +731,7 @@ int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long long *o
     if (stride < 12) return fail(ctx, GPSCAL_EINVAL, "stride_bytes must be >= 12");
     InArg<char> raw;
     GPSCAL_HIP(ctx, raw.bind(ctx, static_cast<const char *>(xyz) + (size_t)off[0] * stride, (size_t)total * stride));
-    GPSCAL_HIP(ctx, gs.pts4.alloc((size_t)total));
+    GPSCAL_HIP(ctx, gs.pooled ? gs.pts4.alloc_async((size_t)total, ctx->stream) : gs.pts4.alloc((size_t)total));
     DevBuf<long long> d_off;
     GPSCAL_HIP(ctx, d_off.alloc_async(npairs + 1, ctx->stream));
     std::vector<long long> rel(npairs + 1);
@@ -797,15 +797,16 @@ int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long long *o
     if (sorted_total >= (1ll << 32) - 1) return fail(ctx, GPSCAL_ERANGE, "batch too large for 32-bit cell offsets");
     gs.total_cells = cells;
     gs.total_sorted = sorted_total;
-    GPSCAL_HIP(ctx, gs.pairs.alloc(npairs));
+    GPSCAL_HIP(ctx, gs.pooled ? gs.pairs.alloc_async(npairs, ctx->stream) : gs.pairs.alloc(npairs));
     GPSCAL_HIP(ctx, hipMemcpyAsync(gs.pairs.p, gs.hpairs.data(), sizeof(PairDesc) * npairs, hipMemcpyHostToDevice,
                                    ctx->stream));
     DevBuf<unsigned> counts;
     GPSCAL_HIP(ctx, counts.alloc_async((size_t)cells + 1, ctx->stream));
-    GPSCAL_HIP(ctx, gs.cell_start_buf.alloc((size_t)cells + 1 + 8));
+    GPSCAL_HIP(ctx, gs.pooled ? gs.cell_start_buf.alloc_async((size_t)cells + 1 + 8, ctx->stream)
+                              : gs.cell_start_buf.alloc((size_t)cells + 1 + 8));
     GPSCAL_HIP(ctx, hipMemsetAsync(gs.cell_start_buf.p, 0, sizeof(unsigned) * ((size_t)cells + 9), ctx->stream));
     gs.cell_start = gs.cell_start_buf.p + 4;
-    GPSCAL_HIP(ctx, gs.sorted.alloc((size_t)sorted_total));
+    GPSCAL_HIP(ctx, gs.pooled ? gs.sorted.alloc_async((size_t)sorted_total, ctx->stream) : gs.sorted.alloc((size_t)sorted_total));
     GPSCAL_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
     if (npairs > 0 && mmax > 0) {
         int maxlev = 1;
@@ -962,6 +963,7 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
     const int np = B->npairs;
     // spatially group each source cloud by its own level-0 cells
     GridSet sg;
+    sg.pooled = true;  // per-call: blocks of the stream's cache (src4 below takes one of them over)
     int rc = build_grids(ctx, src_xyz, stride, src_off, np, 0.f, 1, sg);
     if (rc) return rc;
     B->total_n = sg.total_sorted;

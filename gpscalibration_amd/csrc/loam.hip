@@ -1181,11 +1181,13 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
 {
     // the kd-trees of the last sweep (setInputCloud, LO:538-539,1119-1120) = two grid sets
     GridSet cg, sg;
+    cg.pooled = sg.pooled = pool_grids();
     int rc = build_grids(ctx, d_clast, 16, coff, nsweeps, 0.f, MAX_LEVELS, cg);
     if (!rc) rc = build_grids(ctx, d_slast, 16, soff, nsweeps, 0.f, MAX_LEVELS, sg);
     if (rc) return rc;
     // one more grid per ring of each last cloud for the adjacent-ring searches (LO:613-677, 769-844)
     GridSet rcg, rsg;
+    rcg.pooled = rsg.pooled = pool_grids();
     DevBuf<int> d_ringc, d_rings;
     bool ring_grids = ring_cnt_c && ring_cnt_s;
     if (ring_grids) {
@@ -1315,6 +1317,7 @@ int loam_mapping_device(gpscal_ctx *ctx, int nsweeps, const MapDesc *descs, cons
 {
     // kdtreeCornerFromMap / kdtreeSurfFromMap (setInputCloud, LM:749-750) = two grid sets
     GridSet cg, sg;
+    cg.pooled = sg.pooled = pool_grids();
     int rc = build_grids(ctx, d_cmap, 16, cmoff, nsweeps, 0.f, MAX_LEVELS, cg);
     if (!rc) rc = build_grids(ctx, d_smap, 16, smoff, nsweeps, 0.f, MAX_LEVELS, sg);
     if (rc) return rc;

@@ -199,3 +199,31 @@ def test_results_do_not_depend_on_uninitialised_device_memory():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0 and "False" not in out and "FAILED" not in out, out[-2000:]
+
+
+def test_scan_batch_and_knn_under_the_system_hip_runtime():
+    """The Python tests bind the HIP runtime PyTorch bundles; a C / C++ caller of libgpscal_hip.so binds the
+    system's ROCm runtime.  Under that runtime the library used to abort in gpscal_knn_build and return stale
+    output buffers when its temporaries came from hipMallocAsync (they come from the library's own per-stream
+    block cache now, csrc/common.hpp): a slice of the k-NN / ICP parity tests must pass in a child process that
+    never loads PyTorch, and graph replays, eager runs and separately built batches must agree bit for bit."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GPSCAL_NO_TORCH="1")
+    sel = "(icp or knn) and not device_pointers and not volume and not largest and not full_size and not ball"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"), "-q", "-x",
+                        "-k", sel, "-p", "no:cacheprovider"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from gpscalibration_amd import Context, synth\n"
+        "assert 'torch' not in sys.modules\n"
+        "ctx = Context(0); tg, to, sr, so, _ = synth.scan_batch(3, 20000)\n"
+        "def run(sb, prof):\n"
+        "    sb.set_pose(None); T, e, _ = sb.icp(12, profile=prof); i, d = sb.correspondences(); return T.copy(), e.copy(), i, d\n"
+        "sb = ctx.scan_batch(tg, to, sr, so); ref = run(sb, False)\n"
+        "same = lambda a, b: all(np.array_equal(x, y) for x, y in zip(a, b))\n"
+        "assert all(same(ref, run(sb, False)) for _ in range(3)) and same(ref, run(sb, True))\n"
+        "s2 = ctx.scan_batch(tg, to, sr, so); assert same(ref, run(s2, True)); print('ok')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stdout.decode()[-3000:]

@@ -213,10 +213,11 @@ def test_icp_full_size_properties(ctx):
 
 @pytest.mark.parametrize("n", [262144, 1048576])
 def test_icp_largest_config_sizes(ctx, n):
-    """BASELINE configs[3] / [4] sizes (262 144 and 1 048 576 points per scan, 20 iterations): the
-    oracle cannot run whole pairs of this size in seconds, so the check is by size-independent
-    properties -- convergence to the generating transform, a proper rotation, and exactness of a
-    random sample of the final correspondences and of stand-alone k = 3 searches against brute force."""
+    """BASELINE configs[3] / [4] sizes (262 144 and 1 048 576 points per scan, 20 iterations), by
+    size-independent properties -- convergence to the generating transform, a proper rotation, and exactness
+    of a random sample of the final correspondences and of stand-alone k = 3 searches against BRUTE FORCE
+    (an oracle that shares no search structure with the product).  The whole-pair comparison with the
+    kd-tree oracle at these sizes is test_icp_full_size_matches_oracle."""
     tgt, src, T_true = synth.scan_pair(n, 1)
     off = np.array([0, n], dtype=np.int64)
     sb = ctx.scan_batch(tgt, off, src, off)
@@ -247,6 +248,31 @@ def test_icp_largest_config_sizes(ctx, n):
     ri, rd = O.knn_brute(tgt, q, 3)
     assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
     index.close()
+
+
+@pytest.mark.parametrize("n,iters,pair", [(65536, 50, 0), (262144, 20, 1), (1048576, 20, 1)])
+def test_icp_full_size_matches_oracle(ctx, n, iters, pair):
+    """BASELINE configs[1] / [3] / [4] sizes against the kd-tree oracle on the WHOLE pair: the run's pose and
+    error history within 1e-5 (float32 rounding of the running pose can flip single correspondences between
+    two exact implementations that add their float64 sums in different orders), and the correspondences of the
+    last iteration -- every point, index and squared distance -- bit-exact against one oracle iteration from
+    the pose the product held before it."""
+    tgt, src, T_true = synth.scan_pair(n, pair)
+    off = np.array([0, n], dtype=np.int64)
+    kd = O.KdTree(tgt)
+    T_ref, hist = kd.icp_run(src, iters)
+    sb = ctx.scan_batch(tgt, off, src, off)
+    T, err, _ = sb.icp(iters)
+    assert np.abs(T[0] - T_ref).max() < 1e-5
+    assert np.abs(err[0] - hist).max() < 1e-5
+    assert np.abs(T[0][:3, :3] - T_true[:3, :3]).max() < 1e-3 and np.abs(T[0][:3, 3] - T_true[:3, 3]).max() < 0.02
+    idx, sqd = sb.correspondences()
+    sb.set_pose(None)
+    T_prev, _, _ = sb.icp(iters - 1)  # the pose the last iteration searched with
+    T_next, e_ref, idx_ref, sqd_ref = kd.icp_iterate(src, T_prev[0])
+    assert np.array_equal(idx, idx_ref) and np.array_equal(sqd, sqd_ref)
+    assert np.abs(T[0] - T_next).max() < 1e-9 and abs(err[0, -1] - e_ref) < 1e-10
+    sb.close()
 
 
 @pytest.mark.parametrize("R", [1, 2, 4])
