@@ -29,6 +29,29 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def workload_name(points, pairs, iters):
+    """Which BASELINE.json configuration the run is."""
+    if points == 65536:
+        return "BASELINE configs[1]: synthetic 65536-point scan pairs, %d ICP iterations each, %d pairs per launch" % (iters, pairs)
+    if points == 262144:
+        return ("BASELINE configs[3] per-GPU share (1000 pairs / 8 GPUs = 125): synthetic 262144-point scan pairs, "
+                "%d ICP iterations each, %d pairs per launch" % (iters, pairs))
+    if points == 1048576:
+        return "BASELINE configs[4] scan size: synthetic 1048576-point scan pairs, %d ICP iterations each, %d pairs per launch" % (iters, pairs)
+    return "synthetic %d-point scan pairs, %d ICP iterations each, %d pairs per launch (not a BASELINE size)" % (points, iters, pairs)
+
+
+def kernel_source_sha16():
+    """Hash of the sources of the dominant kernel: rocprof counters in profiles/ are only quoted for the
+    sources they were collected with."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("knn_icp.hip", "knn_device.hpp", "wave_reduce.hpp"):
+        with open(os.path.join(ROOT, "gpscalibration_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes(npairs, n, m):
     """20 n + 12 m bytes per pair per iteration (read source xyz 12 n, read
     target xyz 12 m, write idx + sqd 8 n)."""
@@ -168,15 +191,19 @@ def loam_chain_bench(ctx, nseg=6, nsweeps=30, n_az=1800):
             "note": "host->device copy of the raw sweeps included; segments advance in lock step"}
 
 
-def raw_to_kml_bench(tmpdir, nbag=2, nsweeps=100, n_az=900):
-    """bag->KML from the raw clouds (BASELINE configs[0]/[2] flavour, synthetic): `nbag` drives of
-    `nsweeps` 16-ring sweeps + a 1 Hz GPRMC log each ... one log here, the bags are consecutive stretches of
-    one street.  GPU: input_data's replay + segmentation + LOAM nodes (gpscal_input_data_run), the long /
-    short track passes and the KML writer, wall seconds.  CPU: the oracle's input_data passes on ONE bag
-    (single thread), scaled by the bag count."""
-    import _oracle as O
+def raw_to_kml_bench(ctx, tmpdir, rank=0, world=1, gather=None, dist=None, bags_per_gpu=2, nsweeps=100, n_az=900):
+    """bag->KML from the raw clouds (BASELINE configs[0]/[2] flavour at N = 1, configs[3]/[4] shape at N > 1;
+    synthetic): `bags_per_gpu` x N drives of `nsweeps` 16-ring sweeps, consecutive stretches of one street, one
+    1 Hz GPRMC log.  Bags are sharded in contiguous blocks over the ranks (parallel.bag_to_kml_sharded): each
+    rank runs input_data's replay + segmentation + the LOAM nodes on its bags (gpscal_input_data_run), the
+    segments' pose chains are exchanged with ONE ragged all-gather through the library's RCCL entry point
+    (gpscal_allgather_chains), and rank 0 runs the long / short track passes, the overlap merge and the KML
+    writer.  CPU (N = 1 only): the oracle's input_data passes on ONE bag (single thread), scaled by the bag count."""
+    import torch
     from gpscalibration_amd import pipeline, synth
-    W = synth.lidar_world(0, length=900.0)
+    from gpscalibration_amd.parallel import bag_to_kml_sharded
+    nbag = bags_per_gpu * world
+    W = synth.lidar_world(0, length=0.8 * nsweeps * nbag + 200.0)
     bags, stamps, xy = [], [], []
     for b in range(nbag):
         sw, st, truth = synth.drive(W, nsweeps, seed=40 + b, n_az=n_az, start=(0.8 * nsweeps * b, 0.0))
@@ -184,25 +211,54 @@ def raw_to_kml_bench(tmpdir, nbag=2, nsweeps=100, n_az=900):
         stamps.append(st + 0.1 * nsweeps * b)
         xy.append(truth[:, :2])
     log = os.path.join(tmpdir, "raw_gps.txt")
-    with open(log, "w") as f:
-        f.write(synth.gprmc_for_path(np.concatenate(stamps), np.concatenate(xy), seed=5, sigma=1.0))
+    if rank == 0:
+        with open(log, "w") as f:
+            f.write(synth.gprmc_for_path(np.concatenate(stamps), np.concatenate(xy), seed=5, sigma=1.0))
+    if world > 1:
+        obj = [log]
+        dist.broadcast_object_list(obj, src=0)  # rank 0's temporary directory (one node)
+        log = obj[0]
+        dist.barrier()
     L, S, OV = 50.0, 22.0, 8.0
-    pipeline.run_sweeps(log, [bags[0][:6]], [stamps[0][:6]], L, S, OV)  # warm-up
+    slam = lambda b, s: ctx.input_data_run(b, s, L, S, OV)  # noqa: E731
+    tracks = lambda g, lo, sh, k0, k1: pipeline.run_tracks(g, lo, sh, kml_original=k0, kml_calibrated=k1)  # noqa: E731
+    ctx.input_data_run([bags[0][:6]], [stamps[0][:6]], L, S, OV)  # warm-up
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
-    r = pipeline.run_sweeps(log, bags, stamps, L, S, OV, kml_original=os.path.join(tmpdir, "o.kml"),
-                            kml_calibrated=os.path.join(tmpdir, "c.kml"))
+    r = bag_to_kml_sharded(bags, stamps, log, slam, tracks, rank, world, gather,
+                           os.path.join(tmpdir, "o.kml") if rank == 0 else "", os.path.join(tmpdir, "c.kml") if rank == 0 else "")
     dt = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    O.input_data_pass(bags[0], stamps[0], L, 0.0)
-    O.input_data_pass(bags[0], stamps[0], S, OV)
-    dc = time.perf_counter() - t0
-    return {"workload": "%d bags x %d sweeps (%d points each), long/short/overlap %g/%g/%g m, synthetic"
-                        % (nbag, nsweeps, len(bags[0][0]), L, S, OV),
-            "gpu_wall_s": dt, "gpu_slam_s": r["seconds"][0], "gpu_track_and_kml_s": r["seconds"][4] - r["seconds"][0],
-            "tracks": r["counts"][:2], "cpu_port_slam_s_est": dc * nbag, "cpu_cores": 1,
-            "cpu_sample": "oracle input_data passes (long + short) on one bag: %.1f s" % dc,
-            "note": "the reference replays one cloud per second over two passes (input_data.cpp:32,266): "
-                    ">= %d s for this input regardless of hardware" % (2 * nbag * nsweeps)}
+    ranks_seen = 1
+    if world > 1:
+        v = torch.tensor([dt, r["seconds"][0], r["seconds"][1], r["seconds"][2], 1.0 if r["seconds"][0] > 0 else 0.0],
+                         dtype=torch.float64, device="cuda")
+        mx = v.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = v.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt, slam_s, xchg_s, glob_s = (float(x) for x in mx[:4])
+        ranks_seen = int(round(float(sm[4])))
+    else:
+        slam_s, xchg_s, glob_s = r["seconds"]
+    if rank != 0:
+        return None
+    out = {"workload": "%d bags x %d sweeps (%d points each), long/short/overlap %g/%g/%g m, synthetic"
+                       % (nbag, nsweeps, len(bags[0][0]), L, S, OV),
+           "n_gpus": world, "ranks_seen": ranks_seen, "gpu_wall_s": dt, "gpu_slam_s": slam_s, "exchange_s": xchg_s,
+           "gpu_track_and_kml_s": glob_s, "tracks": r["segments"],
+           "exchange": "gpscal_allgather_chains (RCCL)" if world > 1 else "none (one rank)",
+           "note": "the reference replays one cloud per second over two passes (input_data.cpp:32,266): "
+                   ">= %d s for this input regardless of hardware" % (2 * nbag * nsweeps)}
+    if world == 1:
+        import _oracle as O
+        t0 = time.perf_counter()
+        O.input_data_pass(bags[0], stamps[0], L, 0.0)
+        O.input_data_pass(bags[0], stamps[0], S, OV)
+        dc = time.perf_counter() - t0
+        out.update({"cpu_port_slam_s_est": dc * nbag, "cpu_cores": 1,
+                    "cpu_sample": "oracle input_data passes (long + short) on one bag: %.1f s" % dc})
+    return out
 
 
 def main():
@@ -238,6 +294,21 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = Context(local_rank)
+    # the exchange goes through the library's own RCCL entry point (gpscal_comm_init / gpscal_allgather_chains);
+    # torch.distributed only carries the 128-byte id and the timing reductions
+    lib_gather = None
+    if world > 1:
+        uid = [Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ok = torch.ones(1, device="cuda")
+        try:
+            ctx.comm_init(uid[0], rank, world)
+        except Exception as e:  # noqa: BLE001
+            print("rank %d: gpscal_comm_init failed: %s" % (rank, e), file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0:
+            lib_gather = ctx.allgather_chains
 
     # ---- this rank's shard of the global pair list (weak scaling: args.pairs per GPU)
     total_pairs = args.pairs * world
@@ -251,13 +322,21 @@ def main():
     build_s = sb.build_seconds
     d_T = torch.empty((npairs, 4, 4), dtype=torch.float64, device="cuda")
     d_all = torch.empty((total_pairs, 4, 4), dtype=torch.float64, device="cuda") if world > 1 else d_T
+    pose_counts = np.array([16 * (shard_range(total_pairs, r, world)[1] - shard_range(total_pairs, r, world)[0])
+                            for r in range(world)], dtype=np.int32)
+    from gpscalibration_amd.api import _ptr
 
     def step():
         sb.set_pose(None)
         sb.icp(args.iters, want_err=False, T_out=d_T)
         if world > 1:
-            ctx.sync()  # poses are produced on the library's stream
-            dist.all_gather_into_tensor(d_all.view(-1), d_T.view(-1))
+            if lib_gather is not None:
+                # device pointers in and out: one ncclAllGather on the library's stream
+                ctx._ck(ctx._L.gpscal_allgather_chains(ctx._h, _ptr(d_T), _ptr(pose_counts), _ptr(d_all)), "pose all-gather")
+            else:
+                # d_T is written on the library's stream; the binding has made torch's stream wait for it
+                # (gpscal_make_stream_wait), so the collective needs no host synchronisation
+                dist.all_gather_into_tensor(d_all.view(-1), d_T.view(-1))
 
     def fence():
         ctx.sync()
@@ -290,14 +369,26 @@ def main():
         kern_ms = float(np.mean(ms))
         abytes = algorithmic_bytes(npairs, n, n)
         achieved = abytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        # regimes of the run (same algorithmic bytes): the iterations in which the pose still moves and
+        # most lanes run the grid search, and the converged tail
+        k_search = ms[1:min(8, len(ms))] if len(ms) > 2 else ms
+        k_conv = ms[-min(10, len(ms)):]
+        # the 8n "write idx + sqd" term of the algorithmic bytes is executed by the run's last launch only
+        # (the correspondences are an output of the run, not of every iteration)
+        xbytes = npairs * (12 * n + 12 * n)
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
                     rec = json.load(f)
-                key = "pairs%d_points%d" % (npairs, n)
-                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+                ent = rec.get("pairs%d_points%d" % (npairs, n), {})
+                # counters are only quoted for the kernel sources they were collected with
+                if ent.get("kernel_source_sha16") == kernel_source_sha16():
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/pmc_traffic.json (%s)" % ent.get("collected", "rocprofv3 --pmc")
+                else:
+                    traffic_source = "profiles/pmc_traffic.json is stale for these kernel sources: not quoted"
             except Exception:  # noqa: BLE001
                 traffic = None
         # ---- single-pair latency-bound rate, for DESIGN.md (not `value`)
@@ -321,14 +412,22 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic %d-point scan pairs, %d ICP iterations each"
-                                   % (n, args.iters),
+            "config": {"workload": workload_name(n, npairs, args.iters),
                        "pairs_per_gpu": npairs, "points": n, "iters": args.iters,
-                       "sharding": "scan pairs one batch per GPU; pose all-gather over RCCL"},
+                       "sharding": "scan pairs one batch per GPU; pose all-gather over RCCL (%s)"
+                                   % ("gpscal_allgather_chains" if lib_gather is not None else
+                                      ("torch.distributed" if world > 1 else "one rank: no exchange"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "icp_step_kernel", "avg_launch_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": abytes},
+                         "algorithmic_bytes_per_launch": abytes,
+                         "frac_search": abytes / (float(np.mean(k_search)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_converged": abytes / (float(np.mean(k_conv)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "executed_bytes_per_launch": xbytes,
+                         "frac_executed_bytes": xbytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "frac counts the 8n bytes of idx + sqd per launch as SURVEY 8(d) defines the "
+                                 "iteration; they are written by the last launch of a run only, frac_executed_bytes "
+                                 "leaves them out"},
             "index_build_s": build_s,
             "value_incl_build": total_pairs * args.iters * args.steps / (dt + build_s * args.steps),
             "single_pair_iters_per_s": single,
@@ -341,12 +440,23 @@ def main():
         if world == 1 and not args.no_track:
             import tempfile
             with tempfile.TemporaryDirectory() as td:
-                out["bag_to_kml"] = track_path_bench(td)
-                if not args.no_loam:
-                    out["raw_sweeps_to_kml"] = raw_to_kml_bench(td)
+                out["track_path"] = track_path_bench(td)
+    # bag -> KML, sharded over all ranks (every rank takes part; rank 0 reports)
+    if not args.no_track and not args.no_loam:
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            gather = lib_gather
+            if world > 1 and gather is None:
+                from gpscalibration_amd.parallel import gather_doubles_dist
+                gather = gather_doubles_dist(dist)
+            res = raw_to_kml_bench(ctx, td, rank, world, gather, dist if world > 1 else None)
+            if out is not None:
+                out["bag_to_kml"] = res
     sb.close()
     if world > 1:
         dist.barrier()
+        if lib_gather is not None:
+            ctx.comm_destroy()
         dist.destroy_process_group()
     ctx.close()
     if out is not None:

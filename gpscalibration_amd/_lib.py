@@ -6,7 +6,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 EXPORTS = [
-    "gpscal_create", "gpscal_destroy", "gpscal_sync", "gpscal_stream", "gpscal_strerror",
+    "gpscal_create", "gpscal_destroy", "gpscal_sync", "gpscal_stream", "gpscal_wait_for_stream",
+    "gpscal_make_stream_wait", "gpscal_strerror",
     "gpscal_last_error", "gpscal_device_info",
     "gpscal_weights_speed", "gpscal_weights_irls",
     "gpscal_track_fit", "gpscal_track_fit_batched", "gpscal_long_segment", "gpscal_long_segment_batched",
@@ -66,6 +67,8 @@ def load():
     L.gpscal_last_error.argtypes = [vp]
     L.gpscal_stream.restype = vp
     L.gpscal_stream.argtypes = [vp]
+    L.gpscal_wait_for_stream.argtypes = [vp, vp]
+    L.gpscal_make_stream_wait.argtypes = [vp, vp]
     L.gpscal_create.argtypes = [C.POINTER(vp), i, C.c_uint]
     L.gpscal_destroy.argtypes = [vp]
     L.gpscal_sync.argtypes = [vp]

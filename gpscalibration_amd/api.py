@@ -25,11 +25,16 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+_DEVICE_ARG = [False]  # a CUDA tensor went into the argument list being built (see _Ordered)
+
+
 def _ptr(x):
     if x is None:
         return None
     if _is_torch(x):
         assert x.is_contiguous()
+        if x.is_cuda:
+            _DEVICE_ARG[0] = True
         return C.c_void_p(x.data_ptr())
     assert x.flags["C_CONTIGUOUS"]
     return C.c_void_p(x.ctypes.data)
@@ -47,16 +52,43 @@ def _f32(x):
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
+class _Ordered:
+    """The C ABI with stream ordering for torch tensors (include/gpscal.h, conventions): a call that was handed a
+    CUDA tensor first makes the context's stream wait for torch's current stream (the tensor may still be being
+    written by a pending torch kernel) and afterwards makes torch's current stream wait for the context's stream
+    (a tensor the library writes is then safe to use from torch without a host synchronisation)."""
+
+    def __init__(self, L, ctx):
+        self._L, self._ctx = L, ctx
+
+    def __getattr__(self, name):
+        fn = getattr(self._L, name)
+
+        def call(*args):
+            if not _DEVICE_ARG[0]:
+                return fn(*args)
+            _DEVICE_ARG[0] = False
+            import torch
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self._L.gpscal_wait_for_stream(self._ctx._h, stream)
+            rc = fn(*args)
+            self._L.gpscal_make_stream_wait(self._ctx._h, stream)
+            return rc
+
+        return call
+
+
 class Context:
     """One GPU, one HIP stream (gpscal_ctx).  Fails loudly without a gfx950 device."""
 
     def __init__(self, device_id=0):
-        self._L = load()
+        L = load()
         h = C.c_void_p()
-        rc = self._L.gpscal_create(C.byref(h), int(device_id), 0)
+        rc = L.gpscal_create(C.byref(h), int(device_id), 0)
         if rc:
             raise GpscalError(rc, "gpscal_create(device %d)" % device_id)
         self._h = h
+        self._L = _Ordered(L, self)
         self.device_id = device_id
 
     def close(self):
@@ -313,6 +345,33 @@ class Context:
                  "input_data_run")
         return [{"flag": int(flag[k]), "bag": int(bag[k]), "first": int(first[k]), "last": int(last[k]),
                  "track": rows[toff[k]:toff[k + 1]].copy()} for k in range(int(nt[0]))]
+
+    # ------------------------------------------------------------ RCCL (exported exchange of SURVEY 8e)
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id; rank 0 creates it and hands it to the other ranks out of band."""
+        buf = (C.c_char * 128)()
+        rc = load().gpscal_comm_unique_id(buf)
+        if rc:
+            raise GpscalError(rc, "gpscal_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, uid, rank, world):
+        buf = (C.c_char * 128).from_buffer_copy(bytes(uid))
+        self._ck(self._L.gpscal_comm_init(self._h, buf, int(rank), int(world)), "gpscal_comm_init")
+
+    def comm_destroy(self):
+        self._ck(self._L.gpscal_comm_destroy(self._h), "gpscal_comm_destroy")
+
+    def allgather_chains(self, local, counts):
+        """Ragged all-gather of float64 values over RCCL (gpscal_allgather_chains): `local` holds counts[rank]
+        doubles, every rank gets all sum(counts) in rank order."""
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        local = np.ascontiguousarray(local, dtype=np.float64).reshape(-1)
+        out = np.empty(int(counts.sum()), dtype=np.float64)
+        self._ck(self._L.gpscal_allgather_chains(self._h, _ptr(local) if len(local) else None, _ptr(counts), _ptr(out)),
+                 "gpscal_allgather_chains")
+        return out
 
     def mars(self, lonlat, which):
         """GCJ-02 / BD-09 conversions of [n,2] {lon, lat}: which = "gps_to_gcj" | "gcj_to_bd" | "bd_to_gcj"."""

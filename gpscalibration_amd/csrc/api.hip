@@ -61,6 +61,7 @@ extern "C" int gpscal_destroy(gpscal_ctx *ctx)
     if (!ctx) return GPSCAL_EINVAL;
     (void)hipSetDevice(ctx->device);
     if (ctx->comm) (void)gpscal_comm_destroy(ctx);
+    if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
         cache_trim(ctx->stream);  // the stream's cached temporaries go back to the driver
@@ -79,6 +80,30 @@ extern "C" int gpscal_sync(gpscal_ctx *ctx)
 }
 
 extern "C" void *gpscal_stream(gpscal_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+static int order_streams(gpscal_ctx *ctx, hipStream_t first, hipStream_t then)
+{
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->order_event) GPSCAL_HIP(ctx, hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming));
+    // the wait captures the event's state when it is enqueued: one event serves every call
+    GPSCAL_HIP(ctx, hipEventRecord(ctx->order_event, first));
+    GPSCAL_HIP(ctx, hipStreamWaitEvent(then, ctx->order_event, 0));
+    return GPSCAL_OK;
+}
+
+extern "C" int gpscal_wait_for_stream(gpscal_ctx *ctx, void *producer_stream)
+{
+    if (!ctx) return GPSCAL_EINVAL;
+    if ((hipStream_t)producer_stream == ctx->stream) return GPSCAL_OK;
+    return order_streams(ctx, (hipStream_t)producer_stream, ctx->stream);
+}
+
+extern "C" int gpscal_make_stream_wait(gpscal_ctx *ctx, void *consumer_stream)
+{
+    if (!ctx) return GPSCAL_EINVAL;
+    if ((hipStream_t)consumer_stream == ctx->stream) return GPSCAL_OK;
+    return order_streams(ctx, ctx->stream, (hipStream_t)consumer_stream);
+}
 
 extern "C" const char *gpscal_last_error(gpscal_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "no context"; }
 
@@ -195,6 +220,10 @@ extern "C" int gpscal_allgather_chains(gpscal_ctx *ctx, const double *local, con
         offs[k + 1] = offs[k] + (size_t)counts[k];
     }
     total = offs[W];
+    if (!local && counts[ctx->rank] > 0) return fail(ctx, GPSCAL_EINVAL, "gpscal_allgather_chains: local is NULL");
+    // test hook: take the grouped-broadcast (ragged) path even when the counts are equal, so that a
+    // one-rank box can run it
+    if (getenv("GPSCAL_COMM_FORCE_RAGGED")) equal = false;
     InArg<double> in;
     OutArg<double> out;
     GPSCAL_HIP(ctx, in.bind(ctx, local, (size_t)counts[ctx->rank]));

@@ -20,6 +20,7 @@
 struct gpscal_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t order_event = nullptr;  // gpscal_wait_for_stream / gpscal_make_stream_wait
     hipDeviceProp_t prop{};
     std::string last_error;
     void *comm = nullptr;  // ncclComm_t, owned by comm.hip

@@ -76,3 +76,58 @@ def loam_run_sharded(ctx, segments, stamps, dist=None):
     full = gather_segment_results(t, lens, rank, world, dist).cpu().numpy()
     starts = np.r_[0, np.cumsum(lens)]
     return [full[starts[s]:starts[s + 1]] for s in range(nseg)]
+
+
+def gather_doubles_dist(dist):
+    """gather(local, counts) over torch.distributed (gloo on CPU, nccl = RCCL on GPU): the transport of the
+    tests; the product's transport is Context.allgather_chains (the exported RCCL path)."""
+    import torch
+
+    def gather(local, counts):
+        t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64).reshape(-1))
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        return allgather_ragged(t, [int(c) for c in counts], dist).cpu().numpy()
+
+    return gather
+
+
+def bag_to_kml_sharded(bags, stamps, gps_log, slam, tracks, rank=0, world=1, gather=None, kml_original="",
+                       kml_calibrated=""):
+    """bag -> KML with the SLAM stage sharded over ranks (BASELINE configs[3] / [4]).
+
+    Units = bags (a bag's segments are cut online from its own track, input_data.cpp:78-124, so a bag is the
+    smallest independent piece; LOAM restarts per segment anyway).  Rank r runs `slam` on its contiguous block of
+    bags; the pose chains of every long / short segment are exchanged with ONE ragged all-gather (`gather`, three
+    calls: sizes, segment headers, rows); then the global track alignment -- long pass (GPS weights), short pass
+    (fits), overlap merge (short_distance_track_process.cpp:73-158) and the KML writer -- runs on rank 0 through
+    `tracks`.  Segments are put into (pass, bag, first sweep) order before the global stage, so the files do not
+    depend on the number of ranks.
+
+    slam(bags, stamps) -> list of dict(flag, bag, first, track[n,4])   (Context.input_data_run partially applied)
+    tracks(gps_log, longs, shorts, kml_original, kml_calibrated) -> anything   (pipeline.run_tracks)
+    gather(local_doubles, counts) -> all doubles in rank order              (Context.allgather_chains)
+    Returns dict(seconds=[slam, exchange, global], segments=[long, short], result=tracks(...) on rank 0)."""
+    import time
+    t0 = time.perf_counter()
+    lo, hi = shard_range(len(bags), rank, world)
+    mine = slam(bags[lo:hi], stamps[lo:hi]) if hi > lo else []
+    mine = [t for t in mine if len(t["track"])]
+    t1 = time.perf_counter()
+    head = np.array([[t["flag"], lo + t["bag"], t["first"], len(t["track"])] for t in mine], dtype=np.float64).reshape(-1)
+    rows = (np.concatenate([t["track"] for t in mine]) if mine else np.zeros((0, 4))).reshape(-1)
+    if world > 1:
+        sizes = gather(np.array([len(mine), len(rows) // 4], dtype=np.float64), [2] * world).reshape(world, 2).astype(np.int64)
+        head = gather(head, [4 * int(c) for c in sizes[:, 0]])
+        rows = gather(rows, [4 * int(c) for c in sizes[:, 1]])
+    head = head.reshape(-1, 4)
+    rows = rows.reshape(-1, 4)
+    t2 = time.perf_counter()
+    starts = np.r_[0, np.cumsum(head[:, 3].astype(np.int64))]
+    segs = [(int(h[0]), int(h[1]), int(h[2]), rows[starts[k]:starts[k + 1]]) for k, h in enumerate(head)]
+    segs.sort(key=lambda s: s[:3])
+    longs = [s[3] for s in segs if s[0] == 0]
+    shorts = [s[3] for s in segs if s[0] == 1]
+    result = tracks(gps_log, longs, shorts, kml_original, kml_calibrated) if rank == 0 else None
+    t3 = time.perf_counter()
+    return {"seconds": [t1 - t0, t2 - t1, t3 - t2], "segments": [len(longs), len(shorts)], "result": result}

@@ -27,10 +27,17 @@
  *   - a pointer may address HOST memory or DEVICE (HBM) memory: the library asks
  *     the HIP runtime (hipPointerGetAttributes) and stages host buffers through
  *     the context.  Device pointers are used in place, with no copy;
- *   - all work is issued on the context's HIP stream; calls that hand results
- *     to host memory synchronise that stream before returning, calls whose
- *     outputs are all device pointers return as soon as the work is enqueued
- *     (use gpscal_sync);
+ *   - all work is issued on the context's HIP stream (created non-blocking: it
+ *     does not synchronise with the null stream); calls that hand results to
+ *     host memory synchronise that stream before returning, calls whose outputs
+ *     are all device pointers return as soon as the work is enqueued;
+ *   - DEVICE-pointer arguments carry no ordering of their own.  A device INPUT
+ *     must be complete, or ordered before the context's stream, when the call
+ *     is made: either the producer has been synchronised, or
+ *     gpscal_wait_for_stream(ctx, producer_stream) was called first.  A device
+ *     OUTPUT is ready only after gpscal_sync(ctx), or for work enqueued on a
+ *     stream that was passed to gpscal_make_stream_wait(ctx, consumer_stream)
+ *     after the call, or on the stream gpscal_stream(ctx) returns;
  *   - a context is bound to one GPU and one host thread at a time (the
  *     reference's nodes are single-threaded: LD:128-132, SD:223-231);
  *   - there is NO CPU fallback: without a usable gfx950 device gpscal_create
@@ -75,6 +82,13 @@ int gpscal_destroy(gpscal_ctx *ctx);
 int gpscal_sync(gpscal_ctx *ctx);
 /* The context's hipStream_t, for callers that bracket work with HIP events. */
 void *gpscal_stream(gpscal_ctx *ctx);
+/* Stream ordering for device-pointer arguments (hipStream_t passed as void*; NULL = the
+ * null stream).  wait_for_stream: work enqueued on the context's stream after this call
+ * starts only when everything queued on `producer_stream` so far has finished.
+ * make_stream_wait: work enqueued on `consumer_stream` after this call starts only when
+ * everything queued on the context's stream so far has finished.  Neither blocks the host. */
+int gpscal_wait_for_stream(gpscal_ctx *ctx, void *producer_stream);
+int gpscal_make_stream_wait(gpscal_ctx *ctx, void *consumer_stream);
 const char *gpscal_strerror(int code);
 const char *gpscal_last_error(gpscal_ctx *ctx);
 /* "gfx950", CU count, library version; for logs. */

@@ -51,3 +51,90 @@ def test_loam_chain_sharded_over_two_ranks(tmp_path):
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+_KML_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["GPSCAL_ROOT"])
+from gpscalibration_amd import Context, pipeline, synth
+from gpscalibration_amd.parallel import bag_to_kml_sharded, gather_doubles_dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+out = os.environ["GPSCAL_OUT"]
+W = synth.lidar_world(0, length=400.0)
+bags, stamps, xy = [], [], []
+for b, n in enumerate((60, 44, 52)):
+    sw, st, truth = synth.drive(W, n, seed=70 + b, n_az=450, start=(48.0 * b, 0.0))
+    bags.append(sw); stamps.append(st + 6.0 * b); xy.append(truth[:, :2])
+log = out + ".gps.txt"
+if rank == 0:
+    open(log, "w").write(synth.gprmc_for_path(np.concatenate(stamps), np.concatenate(xy), seed=5, sigma=1.0))
+dist.barrier()
+ctx = Context(0)
+L, S, OV = 20.0, 9.0, 3.0
+slam = lambda b, s: ctx.input_data_run(b, s, L, S, OV)
+tracks = lambda g, lo, sh, k0, k1: pipeline.run_tracks(g, lo, sh, kml_original=k0, kml_calibrated=k1)
+r = bag_to_kml_sharded(bags, stamps, log, slam, tracks, rank, world, gather_doubles_dist(dist), out + ".ori.kml", out + ".cal.kml")
+if rank == 0:
+    r1 = bag_to_kml_sharded(bags, stamps, log, slam, tracks, 0, 1, None, out + ".ref.ori.kml", out + ".ref.cal.kml")
+    assert r1["segments"] == r["segments"] and r["segments"][0] >= 3 and r["segments"][1] >= 6, r["segments"]
+    for ext in (".ori.kml", ".cal.kml"):
+        a, b = open(out + ext, "rb").read(), open(out + ".ref" + ext, "rb").read()
+        assert len(a) > 500 and a == b, ext
+dist.barrier()
+dist.destroy_process_group()
+ctx.close()
+print("rank %d ok" % rank)
+'''
+
+
+def test_bag_to_kml_sharded_over_two_ranks(tmp_path):
+    """BASELINE configs[3] / [4] shape on the one-GPU box: three bags over two ranks (both on GPU 0, exchange over
+    gloo), each rank runs input_data's replay + the LOAM nodes on its bags, ONE ragged exchange of the segments'
+    pose chains, global long / short passes + merge + KML on rank 0.  The files must equal the single-process
+    run byte for byte."""
+    script = tmp_path / "worker.py"
+    script.write_text(_KML_WORKER)
+    env = dict(os.environ, GPSCAL_ROOT=ROOT, GPSCAL_OUT=str(tmp_path / "kml"), MASTER_ADDR="127.0.0.1", MASTER_PORT="29537")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29537", str(script)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_rccl_allgather_chains_ragged_path_world_of_one(monkeypatch):
+    """The exported RCCL exchange (gpscal_comm_init / gpscal_allgather_chains) on the one-GPU box: the ragged
+    branch (grouped ncclBroadcast, in place) forced by GPSCAL_COMM_FORCE_RAGGED, three different chain sizes,
+    host and device buffers.  N > 1 runs only in the driver's multi-GPU bench (bench.py routes its gather
+    through this entry point); until then it is unverified beyond one rank (DESIGN.md section 7)."""
+    from gpscalibration_amd import Context, GpscalError
+    ctx = Context(0)
+    try:
+        ctx.comm_init(Context.comm_unique_id(), 0, 1)
+    except GpscalError as e:
+        ctx.close()
+        pytest.skip("RCCL not usable here: %s" % e)
+    rng = np.random.default_rng(3)
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("GPSCAL_COMM_FORCE_RAGGED", "1")
+        for n in (4, 4 * 1237, 4 * 100003):
+            local = rng.normal(size=n)
+            got = ctx.allgather_chains(local, [n])
+            assert np.array_equal(got, local), (force, n)
+        assert len(ctx.allgather_chains(np.zeros(0), [0])) == 0
+    import torch
+    d_in = torch.from_numpy(rng.normal(size=4096)).cuda()
+    d_out = torch.empty(4096, dtype=torch.float64, device="cuda")
+    from gpscalibration_amd.api import _ptr
+    cnt = np.array([4096], dtype=np.int32)
+    ctx._ck(ctx._L.gpscal_allgather_chains(ctx._h, _ptr(d_in), _ptr(cnt), _ptr(d_out)), "allgather device")
+    assert torch.equal(d_in, d_out)
+    with pytest.raises(GpscalError):  # NULL local with a non-zero count
+        ctx._ck(ctx._L.gpscal_allgather_chains(ctx._h, None, _ptr(cnt), _ptr(d_out)), "allgather null")
+    ctx.comm_destroy()
+    ctx.close()

@@ -121,6 +121,32 @@ def test_knn_device_pointers(ctx):
     ix.close()
 
 
+def test_device_tensors_are_ordered_against_pending_torch_work(ctx):
+    """include/gpscal.h: device-pointer arguments carry no ordering of their own.  The Python binding orders
+    them (gpscal_wait_for_stream before the call, gpscal_make_stream_wait after it): a query tensor that a
+    torch kernel queued behind milliseconds of other work is still writing, and result tensors read back
+    through torch without any host synchronisation, must give the oracle's answer."""
+    torch = pytest.importorskip("torch")
+    tgt = synth.scan_scene(8192, 3)
+    q = synth.scan_scene(4096, 4)
+    d_t = torch.from_numpy(tgt).cuda()
+    q_dev = torch.from_numpy(q).cuda()
+    d_q = torch.zeros((4096, 3), dtype=torch.float32, device="cuda")  # wrong until the pending copy has run
+    big = torch.randn(4096, 4096, device="cuda")
+    ix = ctx.knn_index(d_t)
+    d_i = torch.empty((4096, 1), dtype=torch.int32, device="cuda")
+    d_d = torch.empty((4096, 1), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(30):  # milliseconds of queued work on torch's stream ...
+        big = torch.tanh(big @ big)
+    d_q.copy_(q_dev)  # ... and behind it the kernel that produces the query
+    ix.search(d_q, 1, out_idx=d_i, out_sqd=d_d)  # no ctx.sync(), no torch.cuda.synchronize()
+    got_i, got_d = d_i.cpu().numpy(), d_d.cpu().numpy()
+    ridx, rsqd = O.KdTree(tgt).search(q, 1)
+    assert np.array_equal(got_i, ridx) and np.array_equal(got_d, rsqd)
+    ix.close()
+
+
 # --------------------------------------------------------------------- ICP
 def test_icp_single_iteration_matches_oracle(ctx):
     tgt, src, _ = synth.scan_pair(16384, 0)

@@ -125,3 +125,91 @@ def test_rosbag_reader_round_trip(tmp_path):
     notbag.write_bytes(b"hello")
     with pytest.raises(RuntimeError):
         pipeline.read_bag(str(notbag))
+
+
+_KML_WORKER = r'''
+import os, sys, pickle
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["GPSCAL_ROOT"]); sys.path.insert(0, os.path.join(os.environ["GPSCAL_ROOT"], "tests"))
+from gpscalibration_amd.parallel import bag_to_kml_sharded, gather_doubles_dist
+from test_host_cpu import _fake_slam, _oracle_tracks
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+bags, gprmc = pickle.load(open(os.environ["GPSCAL_CASE"], "rb"))
+out = os.environ["GPSCAL_OUT"]
+r = bag_to_kml_sharded(bags, [None] * len(bags), gprmc, _fake_slam, _oracle_tracks, rank, world, gather_doubles_dist(dist),
+                       out + ".ori.kml", out + ".cal.kml")
+assert (r["result"] is not None) == (rank == 0)
+dist.barrier()
+dist.destroy_process_group()
+print("rank %d ok segments %s" % (rank, r["segments"]))
+'''
+
+
+def _fake_slam(bags, stamps):
+    """SLAM stage stand-in of the orchestration test: a "bag" already holds its pose chains."""
+    out = []
+    for j, b in enumerate(bags):
+        out += [{"flag": 0, "bag": j, "first": k, "track": t} for k, t in b["longs"]]
+        out += [{"flag": 1, "bag": j, "first": k, "track": t} for k, t in b["shorts"]]
+    return out
+
+
+def _oracle_tracks(gprmc, longs, shorts, kml_original, kml_calibrated):
+    """Global stage of the orchestration test on the CPU: the oracle's long pass, short pass, merge and KML."""
+    import _oracle as O
+    total = []
+    for sg in longs:
+        lat, lon, t = O.parse_gprmc(gprmc, sg[0, 3], sg[-1, 3])
+        enu = O.gps_to_enu(lat, lon, t, sg)
+        w, _ = O.long_segment(sg[:len(enu)], enu, 5)
+        total.append(np.c_[enu, w])
+    gps = np.concatenate(total)
+    acc = None
+    for sg in shorts:
+        so, go, wo = O.match_gps(gps, sg)
+        _, _, cal, _ = O.track_fit(so, go, wo)
+        acc = O.merge_short(acc, cal, wo)
+    ll0, alt0 = O.local_to_wgs(gps)
+    ll1, alt1 = O.local_to_wgs(acc)
+    end1, rgb1 = O.colour_segments(acc)
+    open(kml_original, "w").write(O.kml(ll0, alt0, 0))
+    open(kml_calibrated, "w").write(O.kml(ll1, alt1, 1, end1, rgb1))
+    return len(gps), len(acc)
+
+
+def test_bag_to_kml_orchestration_gloo_world2(tmp_path):
+    """N > 1 path of bag -> KML (parallel.bag_to_kml_sharded): bags sharded in contiguous blocks, ONE ragged
+    exchange of the segments' pose chains, global track alignment + KML on rank 0.  Two gloo ranks must write
+    the files a single process writes, byte for byte (SLAM stand-in: precomputed chains; global stage: the
+    oracle -- there is no GPU here; tests/test_gpu_multi.py runs the same function with the product's stages)."""
+    import pickle
+    from gpscalibration_amd import synth
+    from gpscalibration_amd.parallel import bag_to_kml_sharded
+    longs, shorts, gprmc = synth.segmented_run(2400, 600, 200, 60, seed=5, dropout=0.2)
+    nb = 3  # bags of unequal size: 1, 1 and the rest of the long segments; shorts by time span
+    cut = [longs[0][0, 3], longs[1][0, 3], longs[2][0, 3], np.inf]
+    bags = []
+    for b in range(nb):
+        lg = [(k, t) for k, t in enumerate(longs) if cut[b] <= t[0, 3] < cut[b + 1]]
+        sh = [(k, t) for k, t in enumerate(shorts) if cut[b] <= t[0, 3] < cut[b + 1]]
+        bags.append({"longs": lg, "shorts": sh})
+    assert sum(len(b["longs"]) for b in bags) == len(longs) and sum(len(b["shorts"]) for b in bags) == len(shorts)
+    ref = str(tmp_path / "ref")
+    r1 = bag_to_kml_sharded(bags, [None] * nb, gprmc, _fake_slam, _oracle_tracks, 0, 1, None, ref + ".ori.kml", ref + ".cal.kml")
+    assert r1["segments"] == [len(longs), len(shorts)]
+    case = tmp_path / "case.pkl"
+    pickle.dump((bags, gprmc), open(case, "wb"))
+    script = tmp_path / "worker.py"
+    script.write_text(_KML_WORKER)
+    out = str(tmp_path / "w2")
+    env = dict(os.environ, GPSCAL_ROOT=ROOT, GPSCAL_CASE=str(case), GPSCAL_OUT=out, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29519", str(script)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    for ext in (".ori.kml", ".cal.kml"):
+        a, b = open(ref + ext, "rb").read(), open(out + ext, "rb").read()
+        assert len(a) > 1000 and a == b, ext
