@@ -163,6 +163,42 @@ def track_path_bench(tmpdir, total_poses=400000, long_len=1200, short_len=400, o
             "note": "the reference additionally replays one cloud per second (input_data.cpp:32,333): its wall time is >= 2 x #clouds s"}
 
 
+def large_demo_bench(tmpdir):
+    """BASELINE configs[2] substitute (SURVEY 8d "large-demo-like"): SLAM segments derived from the GPRMC log the
+    reference ships (2 490 fixes; tests/golden/original_gps_data.txt is a byte copy of its data file), cut at run.sh's
+    1000 / 300 / 100 m, through the long / short track passes and the KML writer; the CPU port on the same input."""
+    import _oracle as O
+    from gpscalibration_amd import pipeline, synth
+    path = os.path.join(ROOT, "tests", "golden", "original_gps_data.txt")
+    with open(path, newline="") as f:
+        gprmc = f.read()
+    longs, shorts = synth.large_demo_like(gprmc)
+    k0, k1 = os.path.join(tmpdir, "ld_ori.kml"), os.path.join(tmpdir, "ld_cal.kml")
+    pipeline.run_tracks(path, longs[:1], shorts[:2])
+    r = min((pipeline.run_tracks(path, longs, shorts, kml_original=k0, kml_calibrated=k1) for _ in range(3)),
+            key=lambda x: x["seconds"][3])
+    t0 = time.perf_counter()
+    total = []
+    for sg in longs:
+        lat, lon, t = O.parse_gprmc(gprmc, sg[0, 3], sg[-1, 3])
+        enu = O.gps_to_enu(lat, lon, t, sg)
+        w, _ = O.long_segment(sg[:len(enu)], enu, 5)
+        total.append(np.c_[enu, w])
+    gps = np.concatenate(total)
+    acc = None
+    for sg in shorts:
+        so, go, wo = O.match_gps(gps, sg)
+        _, _, cal, _ = O.track_fit(so, go, wo)
+        acc = O.merge_short(acc, cal, wo)
+    dc = time.perf_counter() - t0
+    return {"workload": "BASELINE configs[2] substitute: %d fixes of the shipped GPRMC log, %d long + %d short segments "
+                        "derived from it (%d poses), run.sh distances 1000/300/100 m"
+                        % (gprmc.count("$GPRMC"), len(longs), len(shorts), sum(len(s) for s in longs)),
+            "gpu_wall_s": r["seconds"][3], "gpu_long_pass_s": r["seconds"][0], "gpu_short_pass_s": r["seconds"][1],
+            "gpu_output_s": r["seconds"][2], "points": r["points"], "cpu_port_wall_s": dc, "cpu_cores": 1,
+            "note": "track path only: the bags of large_size_demo_data are an external download (README.md:65-66)"}
+
+
 def loam_chain_bench(ctx, nseg=6, nsweeps=30, n_az=1800):
     """The LOAM node chain ahead of the track path: raw 16-ring sweeps of
     `nseg` synthetic drives -> /true_odometry_to_init samples, all segments in lock step on the GPU;
@@ -441,6 +477,7 @@ def main():
             import tempfile
             with tempfile.TemporaryDirectory() as td:
                 out["track_path"] = track_path_bench(td)
+                out["large_demo_like"] = large_demo_bench(td)
     # bag -> KML, sharded over all ranks (every rank takes part; rank 0 reports)
     if not args.no_track and not args.no_loam:
         import tempfile

@@ -19,7 +19,7 @@ EXPORTS = [
     "gpscal_icp_iterate", "gpscal_icp_run",
     "gpscal_loam_odometry_batched", "gpscal_loam_mapping_batched", "gpscal_loam_transform",
     "gpscal_scan_registration_batched", "gpscal_voxel_grid_batched", "gpscal_loam_run_batched", "gpscal_input_data_run",
-    "gpscal_gps_to_gcj", "gpscal_gcj_to_bd", "gpscal_bd_to_gcj",
+    "gpscal_gps_to_gcj", "gpscal_gcj_to_bd", "gpscal_bd_to_gcj", "gpscal_imgps_message",
     "gpscal_comm_unique_id", "gpscal_comm_init", "gpscal_allgather_chains", "gpscal_comm_destroy",
 ]
 
@@ -105,6 +105,7 @@ def load():
                                          dp, i, ip, i, i]
     for name in ("gpscal_gps_to_gcj", "gpscal_gcj_to_bd", "gpscal_bd_to_gcj"):
         getattr(L, name).argtypes = [vp, dp, i, dp]
+    L.gpscal_imgps_message.argtypes = [vp, i, i, dp, i, dp]
     L.gpscal_loam_transform.argtypes = [vp, fp, fp, i, fp, i]
     L.gpscal_comm_unique_id.argtypes = [vp]
     L.gpscal_comm_init.argtypes = [vp, vp, i, i]

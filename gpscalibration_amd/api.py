@@ -373,6 +373,13 @@ class Context:
                  "gpscal_allgather_chains")
         return out
 
+    def imgps_message(self, calibrated_xyztw, method="UTM", band_type=3):
+        """/imorpheus_gps payload (result_control 4, short_distance_track_process.cpp:295-309): [n,3] {b, l, w}."""
+        e = _f64(calibrated_xyztw)
+        out = np.empty((len(e), 3))
+        self._ck(self._L.gpscal_imgps_message(self._h, METHOD[method], band_type, _ptr(e), len(e), _ptr(out)), "imgps_message")
+        return out
+
     def mars(self, lonlat, which):
         """GCJ-02 / BD-09 conversions of [n,2] {lon, lat}: which = "gps_to_gcj" | "gcj_to_bd" | "bd_to_gcj"."""
         p = _f64(lonlat)

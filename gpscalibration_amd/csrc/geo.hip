@@ -305,6 +305,42 @@ extern "C" int gpscal_enu_to_wgs(gpscal_ctx *ctx, int method, int band_type, con
     return GPSCAL_OK;
 }
 
+// IMGPS{b, l, w} per calibrated point (short_distance_track_process.cpp:299-304): l = longitude and b = latitude of
+// the inverse projection, w = the merged weight.
+__global__ void imgps_kernel(int method, int band_type, const double *__restrict__ enu, int n, double *__restrict__ ll,
+                             double *__restrict__ blw)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    blw[3 * i] = ll[2 * i + 1];
+    blw[3 * i + 1] = ll[2 * i];
+    blw[3 * i + 2] = enu[5 * (size_t)i + 4];
+}
+
+extern "C" int gpscal_imgps_message(gpscal_ctx *ctx, int method, int band_type, const double *enu, int n, double *blw)
+{
+    int rc = check_proj(ctx, method, band_type);
+    if (rc) return rc;
+    if (!enu || !blw || n < 1) return fail(ctx, GPSCAL_EINVAL, "gpscal_imgps_message: bad argument");
+    GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
+    InArg<double> a;
+    OutArg<double> o;
+    DevBuf<double> ll, alt;
+    GPSCAL_HIP(ctx, a.bind(ctx, enu, (size_t)n * 5));
+    GPSCAL_HIP(ctx, o.bind(ctx, blw, (size_t)n * 3));
+    GPSCAL_HIP(ctx, ll.alloc_async((size_t)n * 2, ctx->stream));
+    GPSCAL_HIP(ctx, alt.alloc_async((size_t)n, ctx->stream));
+    hipLaunchKernelGGL(enu_to_wgs_kernel, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, method, band_type, a.dev, n,
+                       ll.p, alt.p);
+    hipLaunchKernelGGL(imgps_kernel, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, method, band_type, a.dev, n, ll.p,
+                       o.dev);
+    GPSCAL_HIP(ctx, hipGetLastError());
+    bool sync = a.tmp.p != nullptr;  // a staged input must outlive the kernels
+    GPSCAL_HIP(ctx, o.commit(ctx, &sync));
+    if (sync) GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSCAL_OK;
+}
+
 extern "C" int gpscal_gps_to_enu(gpscal_ctx *ctx, int method, int band_type, const double *lat, const double *lon,
                                  const double *gps_t, int ngps, const double *slam, int nslam, double *enu, int *n_out)
 {

@@ -33,7 +33,14 @@ typedef struct {
     double w;
 } COORDXYZTW;
 
-static_assert(sizeof(COORDXYZT) == 32 && sizeof(COORDXYZTW) == 40, "layouts are part of the C ABI");
+// gpsCalibration/IMGPS (msg/IMGPS.msg): one element of IMMessage.track, the /imorpheus_gps payload
+typedef struct {
+    double b;  // latitude
+    double l;  // longitude
+    double w;  // confidence (merged weight)
+} IMGPS;
+
+static_assert(sizeof(COORDXYZT) == 32 && sizeof(COORDXYZTW) == 40 && sizeof(IMGPS) == 24, "layouts are part of the C ABI");
 
 namespace gpscal_host {
 // The reference's classes take no context argument; they share one process-wide

@@ -366,6 +366,16 @@ int GPSPro::ENUToGPS(std::vector<COORDXYZTW> enu, std::vector<std::pair<double, 
     return 0;
 }
 
+std::vector<IMGPS> GPSPro::calibratedGPSMessage(const std::vector<COORDXYZTW> &calibrated)
+{
+    std::vector<IMGPS> track(calibrated.size());
+    if (calibrated.empty()) return track;
+    check(gpscal_imgps_message(default_ctx(), method == "UTM" ? GPSCAL_METHOD_UTM : GPSCAL_METHOD_GAUSS, type,
+                               &calibrated[0].x, (int)calibrated.size(), &track[0].b),
+          "gpscal_imgps_message");
+    return track;
+}
+
 // --------------------------------------------------------------------- KML
 
 std::vector<std::string> GPSPro::readKMLParameter()

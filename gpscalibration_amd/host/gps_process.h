@@ -29,6 +29,8 @@ public:
     // ENU -> WGS84 + 50 m colour segments (gps_process.cc:374-386, 600-626, 1010-1058)
     int ENUToGPS(std::vector<COORDXYZTW> enuCoor, std::vector<std::pair<double, double> > &WGSBL,
                  std::vector<double> &altitude, std::vector<std::pair<int, std::string> > &segmentColor);
+    // The /imorpheus_gps payload of result_control 4 (short_distance_track_process.cpp:295-309): IMMessage.track
+    std::vector<IMGPS> calibratedGPSMessage(const std::vector<COORDXYZTW> &calibrated);
     // KML writer (gps_process.cc:759-847), flag 0 = original track, 1 = calibrated
     int createKML(std::string KMLFileName, std::vector<std::pair<double, double> > WGSBL, std::vector<double> altitude,
                   int flag, std::vector<std::pair<int, std::string> > segmentColor);

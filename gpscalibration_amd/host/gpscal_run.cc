@@ -313,7 +313,20 @@ int main(int argc, char **argv)
             gps.createJSON(a["gps_improved_filename"], GCJ02, 1, impCol);
             return 0;
         }
-        if (rc == 4) fprintf(stderr, "result_control 4 publishes a ROS message (/imorpheus_gps); without ROS: writing KML\n");
+        if (rc == 4) {  // PUBLISH_MESSAGE, short_distance_track_process.cpp:293-309
+            // the node publishes gpsCalibration/IMMessage on /imorpheus_gps; without ROS the same records go to the
+            // "improved" file, one "b,l,w" line per IMGPS (INTEGRATION.md shows the five-line publisher)
+            const std::vector<IMGPS> track = gps.calibratedGPSMessage(sp.result());
+            FILE *f = fopen(a["gps_improved_filename"].c_str(), "w");
+            if (!f) {
+                fprintf(stderr, "cannot write %s\n", a["gps_improved_filename"].c_str());
+                return 1;
+            }
+            for (size_t i = 0; i < track.size(); ++i) fprintf(f, "%.15g,%.15g,%.15g\n", track[i].b, track[i].l, track[i].w);
+            fclose(f);
+            printf("==================== Start to publish calibrated gps ====================\n");
+            return 0;
+        }
         printf("====================  Create original GPS KML  ====================\n");
         gps.createKML(a["gps_original_filename"], oriWGSBL, oriAlt, 0, oriCol);
         printf("==================== Create calibrated GPS KML ====================\n");

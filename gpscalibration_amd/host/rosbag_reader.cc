@@ -48,6 +48,9 @@ struct Msg {
 };
 
 struct Reader {
+    int pass = 0;  // 0: connection records only (a message may precede its connection record in file order when the
+                   // chunks are not in time order; rosbag itself reads the connection list from the index section),
+                   // 1: message data
     std::string want;  // topic without leading slash
     std::map<uint32_t, bool> conn_wanted;
     std::vector<Msg> msgs;
@@ -102,6 +105,13 @@ struct Reader {
             return false;
         }
         const uint8_t *data = d.p + at;
+        // the layout the message declares must fit its own data block: every field inside a point, every point
+        // inside its row, every row inside the data
+        if (point_step == 0 || (width > 0 && (size_t)width * point_step > row_step))
+            return fail_cloud("PointCloud2 with point_step / row_step that cannot hold a row");
+        for (int a = 0; a < 3; ++a)
+            if ((size_t)off[a] + 4 > point_step) return fail_cloud("PointCloud2 field offset beyond point_step");
+        if ((uint64_t)height * row_step > dlen) return fail_cloud("PointCloud2 data shorter than height x row_step");
         const size_t npts = (size_t)height * width;
         m.stamp = (double)secs + 1e-9 * (double)nsecs;  // ros::Time::toSec
         m.first_point = pts.size() / 3;
@@ -118,6 +128,12 @@ struct Reader {
                 for (int a = 0; a < 3; ++a) memcpy(o++, data + base + off[a], 4);
             }
         return true;
+    }
+
+    bool fail_cloud(const char *what)
+    {
+        err = what;
+        return false;
     }
 
     // records of a chunk body or of the top level
@@ -137,6 +153,7 @@ struct Reader {
             if (!parse_header(h, f) || !f.count("op") || f["op"].n != 1) return fail("bad record header");
             const uint8_t op = f["op"].p[0];
             if (op == 0x07) {  // connection
+                if (pass != 0) continue;
                 if (!f.count("conn") || f["conn"].n != 4 || !f.count("topic")) return fail("bad connection record");
                 std::map<std::string, Span> ch;
                 if (!parse_header(d, ch)) return fail("bad connection header");
@@ -145,6 +162,7 @@ struct Reader {
                 if (ch.count("type")) type.assign((const char *)ch["type"].p, ch["type"].n);
                 conn_wanted[rd32(f["conn"].p)] = strip(topic) == want && type == "sensor_msgs/PointCloud2";
             } else if (op == 0x02) {  // message data
+                if (pass != 1) continue;
                 if (!f.count("conn") || f["conn"].n != 4 || !f.count("time") || f["time"].n != 8) return fail("bad message record");
                 const uint32_t c = rd32(f["conn"].p);
                 if (conn_wanted.count(c) && conn_wanted[c]) {
@@ -158,6 +176,9 @@ struct Reader {
                 if (!f.count("compression") || !f.count("size") || f["size"].n != 4) return fail("bad chunk record");
                 const std::string comp((const char *)f["compression"].p, f["compression"].n);
                 const uint32_t usize = rd32(f["size"].p);
+                // rosbag's chunks are ~768 KiB (at most a few MiB): a size field beyond this is a corrupt file,
+                // not a reason to allocate gigabytes
+                if (usize > (256u << 20)) return fail("chunk size field is implausible (> 256 MiB)");
                 if (comp == "none") {
                     if (!records(d, false)) return false;
                 } else if (comp == "bz2") {
@@ -264,10 +285,11 @@ bool read_bag_clouds(const std::string &path, const std::string &topic, CloudSer
     }
     Reader R;
     R.want = Reader::strip(topic);
-    if (!R.records(Span{file.data() + 13, file.size() - 13}, true)) {
-        err = path + ": " + R.err;
-        return false;
-    }
+    for (R.pass = 0; R.pass < 2; ++R.pass)
+        if (!R.records(Span{file.data() + 13, file.size() - 13}, true)) {
+            err = path + ": " + R.err;
+            return false;
+        }
     // rosbag::View hands messages out by time; equal times keep file order
     std::stable_sort(R.msgs.begin(), R.msgs.end(), [](const Msg &a, const Msg &b) { return a.time < b.time; });
     if (out.sweep_off.empty()) out.sweep_off.push_back(0);

@@ -208,6 +208,63 @@ def segmented_run(total_poses=3000, long_len=1000, short_len=300, overlap=100, s
     return longs, shorts, d["gprmc"]
 
 
+def large_demo_like(gprmc_text, rate_hz=10.0, long_m=1000.0, short_m=300.0, overlap_m=100.0, seed=17, smooth_s=9):
+    """BASELINE configs[2] substitute (SURVEY 8d "large-demo-like"): the bags of large_size_demo_data are an external
+    download, the GPRMC log the reference ships (data/original_gps_data.txt: 2 490 fixes, 41.5 min) is not.  The SLAM
+    side is derived from that log: the fixes are smoothed (moving average over `smooth_s` s), sampled at the sweep rate
+    and cut by travelled distance the way input_data does with run.sh's defaults (long 1000 m; short 300 m with 100 m
+    overlap; a tail shorter than a third of the distance joins the previous segment, input_data.cpp:367-424); every
+    segment is re-based to its first pose with its own unknown heading (LOAM restarts per segment) and carries a little
+    odometry drift.  Returns (longs, shorts): lists of [n,4] {x, y, z = 10, t} arrays."""
+    fixes = []
+    for line in gprmc_text.replace("\r", "\n").split("\n"):
+        f = line.split(",")
+        if len(f) < 8 or f[1] != "$GPRMC" or f[3] != "A":
+            continue
+        la, lo = float(f[4]), float(f[6])
+        lat = int(la / 100) + (la - 100 * int(la / 100)) / 60.0
+        lon = int(lo / 100) + (lo - 100 * int(lo / 100)) / 60.0
+        fixes.append((float(f[0]), lat if f[5] == "N" else -lat, lon if f[7] == "E" else -lon))
+    g = np.array(fixes)
+    x = (g[:, 1] - g[0, 1]) * 111132.0  # northing, easting in metres (the shape matters, not the datum)
+    y = (g[:, 2] - g[0, 2]) * 111320.0 * math.cos(math.radians(g[0, 1]))
+    k = np.ones(smooth_s) / smooth_s
+    pad = smooth_s // 2
+    xs = np.convolve(np.pad(x, pad, mode="edge"), k, mode="valid")
+    ys = np.convolve(np.pad(y, pad, mode="edge"), k, mode="valid")
+    t = np.arange(g[2, 0], g[-3, 0], 1.0 / rate_hz)  # strictly inside the log: interPolate drops later stamps
+    xy = np.c_[np.interp(t, g[:, 0], xs), np.interp(t, g[:, 0], ys)]
+    dist = np.r_[0.0, np.cumsum(np.hypot(np.diff(xy[:, 0]), np.diff(xy[:, 1])))]
+    rng = np.random.default_rng(seed)
+
+    def make(a, b):
+        th = rng.uniform(0, 2 * math.pi)
+        c, s_ = math.cos(th), math.sin(th)
+        loc = xy[a:b] - xy[a] + np.cumsum(rng.normal(0, 0.002, size=(b - a, 2)), axis=0)
+        seg = np.empty((b - a, 4))
+        seg[:, 0] = c * loc[:, 0] - s_ * loc[:, 1]
+        seg[:, 1] = s_ * loc[:, 0] + c * loc[:, 1]
+        seg[:, 2] = 10.0
+        seg[:, 3] = t[a:b]
+        return seg
+
+    def cut(D, ov):
+        out, a, n = [], 0, len(t)
+        while a < n - 1:
+            b = int(np.searchsorted(dist, dist[a] + D, side="right"))
+            if b >= n or dist[-1] - dist[min(b, n - 1)] < D / 3.0:  # a short rest joins this segment
+                b = n
+            out.append((a, b))
+            if b == n:
+                break
+            a = int(np.searchsorted(dist, dist[b - 1] - ov, side="left"))
+        return out
+
+    longs = [make(a, b) for a, b in cut(long_m, 0.0)]
+    shorts = [make(a, b) for a, b in cut(short_m, overlap_m)]
+    return longs, shorts
+
+
 def write_track_file(path, longs, shorts):
     """The driver's track-file format: '<flag> <n>' then n lines 'x y z t'."""
     with open(path, "w") as f:
@@ -453,10 +510,16 @@ def write_sweep_file(path, bags, stamps):
                 f.write(sw.tobytes())
 
 
-def write_rosbag(path, sweeps, stamps, topic="/velodyne_points", chunk_msgs=6, with_ring=True, compression="none"):
+def write_rosbag(path, sweeps, stamps, topic="/velodyne_points", chunk_msgs=6, with_ring=True, compression="none",
+                 publishers=1, foreign=(), chunk_order=None, corrupt=None):
     """Writes a rosbag V2.0 file holding one sensor_msgs/PointCloud2 message per sweep (Velodyne
     layout: x, y, z, intensity float32 + ring uint16, point_step 32), with connection, chunk, index
-    and chunk-info records, as `rosbag record` lays them out.  compression: "none", "bz2" or "lz4"."""
+    and chunk-info records, as `rosbag record` lays them out.  compression: "none", "bz2" or "lz4".
+    publishers > 1: the sweeps alternate between that many connections of the same topic (several publishers);
+    foreign: (topic, type, stamp, payload bytes) messages of other topics, merged in by stamp on connections of
+    their own; chunk_order: permutation of the chunks in the file (a bag recorded out of time order -- every chunk
+    then carries the connection records it needs); corrupt: "field_offset" | "huge_width" | "chunk_size" writes
+    a deliberately malformed file (reader robustness tests)."""
     import bz2
     import struct
 
@@ -477,15 +540,28 @@ def write_rosbag(path, sweeps, stamps, topic="/velodyne_points", chunk_msgs=6, w
         return struct.pack("<I", len(b)) + b
 
     msg_def = "# synthetic\n"
-    conn_hdr = (field("topic", topic.encode()) + field("type", b"sensor_msgs/PointCloud2") +
-                field("md5sum", b"1158d486dd51d683ce2f1be655c3c181") + field("message_definition", msg_def.encode()))
-    conn_rec = record([("op", b"\x07"), ("conn", struct.pack("<I", 0)), ("topic", topic.encode())], conn_hdr)
+
+    def make_conn(cid, tpc, typ):
+        hdr = (field("topic", tpc.encode()) + field("type", typ.encode()) +
+               field("md5sum", b"1158d486dd51d683ce2f1be655c3c181") + field("message_definition", msg_def.encode()))
+        return record([("op", b"\x07"), ("conn", struct.pack("<I", cid)), ("topic", tpc.encode())], hdr)
+
+    conns = {c: make_conn(c, topic, "sensor_msgs/PointCloud2") for c in range(publishers)}
+    ftopics = []
+    for ft, fty, _, _ in foreign:
+        if (ft, fty) not in ftopics:
+            ftopics.append((ft, fty))
+            conns[publishers + len(ftopics) - 1] = make_conn(publishers + len(ftopics) - 1, ft, fty)
 
     def cloud_msg(seq, t, pts):
         n = len(pts)
         body = struct.pack("<I", seq) + ros_time(t) + ros_str("velodyne")
         body += struct.pack("<II", 1, n)
         fields = [("x", 0, 7), ("y", 4, 7), ("z", 8, 7), ("intensity", 16, 7)] + ([("ring", 20, 4)] if with_ring else [])
+        if corrupt == "field_offset" and seq == 1:
+            fields[2] = ("z", 30, 7)  # 30 + 4 > point_step 32
+        if corrupt == "huge_width" and seq == 1:
+            body = body[:-8] + struct.pack("<II", 1, 0x7fffffff)
         body += struct.pack("<I", len(fields))
         for name, off, dt in fields:
             body += ros_str(name) + struct.pack("<IBI", off, dt, 1)
@@ -495,13 +571,23 @@ def write_rosbag(path, sweeps, stamps, topic="/velodyne_points", chunk_msgs=6, w
         body += struct.pack("<BII", 0, step, step * n) + struct.pack("<I", step * n) + data.tobytes() + struct.pack("<B", 1)
         return body
 
+    # all messages in time order: (stamp, connection, payload)
+    allmsgs = [(float(stamps[k]), k % publishers, cloud_msg(k, stamps[k], sweeps[k])) for k in range(len(sweeps))]
+    for ft, fty, fst, fpay in foreign:
+        allmsgs.append((float(fst), publishers + ftopics.index((ft, fty)), bytes(fpay)))
+    allmsgs.sort(key=lambda m: m[0])
     chunks, infos = [], []
-    for c0 in range(0, len(sweeps), chunk_msgs):
-        body, index = conn_rec if c0 == 0 else b"", []
-        for k in range(c0, min(c0 + chunk_msgs, len(sweeps))):
-            index.append((stamps[k], len(body)))
-            body += record([("op", b"\x02"), ("conn", struct.pack("<I", 0)), ("time", ros_time(stamps[k]))],
-                           cloud_msg(k, stamps[k], sweeps[k]))
+    seen = set()
+    for c0 in range(0, len(allmsgs), chunk_msgs):
+        part = allmsgs[c0:c0 + chunk_msgs]
+        body, index = b"", []
+        for cid in sorted(set(m[1] for m in part)):
+            if chunk_order is not None or cid not in seen:  # a shuffled file repeats them in every chunk
+                body += conns[cid]
+                seen.add(cid)
+        for st_, cid, pay in part:
+            index.append((st_, len(body)))
+            body += record([("op", b"\x02"), ("conn", struct.pack("<I", cid)), ("time", ros_time(st_))], pay)
         if compression == "bz2":
             payload = bz2.compress(body)
         elif compression == "lz4":  # roslz4 writes standard LZ4 frames
@@ -517,12 +603,16 @@ def write_rosbag(path, sweeps, stamps, topic="/velodyne_points", chunk_msgs=6, w
             payload = dst.raw[:n]
         else:
             payload = body
-        chunk = record([("op", b"\x05"), ("compression", compression.encode()), ("size", struct.pack("<I", len(body)))], payload)
+        declared = 0xfffffff0 if corrupt == "chunk_size" and c0 == 0 and compression != "none" else len(body)
+        chunk = record([("op", b"\x05"), ("compression", compression.encode()), ("size", struct.pack("<I", declared))], payload)
         idx = record([("op", b"\x04"), ("ver", struct.pack("<I", 1)), ("conn", struct.pack("<I", 0)),
                       ("count", struct.pack("<I", len(index)))],
                      b"".join(ros_time(t) + struct.pack("<I", o) for t, o in index))
         chunks.append(chunk + idx)
         infos.append((index[0][0], index[-1][0], len(index)))
+    if chunk_order is not None:
+        chunks = [chunks[i] for i in chunk_order]
+        infos = [infos[i] for i in chunk_order]
     with open(path, "wb") as f:
         f.write(b"#ROSBAG V2.0\n")
         pos = 13 + 4096
@@ -531,13 +621,14 @@ def write_rosbag(path, sweeps, stamps, topic="/velodyne_points", chunk_msgs=6, w
             chunk_pos.append(pos)
             pos += len(c)
         hdr = b"".join(field(k, v) for k, v in [("op", b"\x03"), ("index_pos", struct.pack("<Q", pos)),
-                                                ("conn_count", struct.pack("<I", 1)),
+                                                ("conn_count", struct.pack("<I", len(conns))),
                                                 ("chunk_count", struct.pack("<I", len(chunks)))])
         pad = 4096 - 4 - len(hdr) - 4
         f.write(struct.pack("<I", len(hdr)) + hdr + struct.pack("<I", pad) + b" " * pad)
         for c in chunks:
             f.write(c)
-        f.write(conn_rec)
+        for cid in sorted(conns):
+            f.write(conns[cid])
         for cp, (t0, t1, cnt) in zip(chunk_pos, infos):
             f.write(record([("op", b"\x06"), ("ver", struct.pack("<I", 1)), ("chunk_pos", struct.pack("<Q", cp)),
                             ("start_time", ros_time(t0)), ("end_time", ros_time(t1)), ("count", struct.pack("<I", 1))],

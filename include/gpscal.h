@@ -275,6 +275,12 @@ int gpscal_loam_transform(gpscal_ctx *ctx, const float *transform6,
 int gpscal_gps_to_gcj(gpscal_ctx *ctx, const double *lonlat, int n, double *gcj_lonlat);
 int gpscal_gcj_to_bd(gpscal_ctx *ctx, const double *gcj_lonlat, int n, double *bd_lonlat);
 int gpscal_bd_to_gcj(gpscal_ctx *ctx, const double *bd_lonlat, int n, double *gcj_lonlat);
+/* The payload of /imorpheus_gps (result_control 4; short_distance_track_process.cpp:295-309): for each of the
+ * n calibrated points (COORDXYZTW, the merged short-pass result) one gpsCalibration/IMGPS record
+ * {b = latitude, l = longitude, w = merged weight} (msg/IMGPS.msg, msg/IMMessage.msg: float64 b, l, w).
+ * blw: n x 3 doubles.  The ROS side only has to copy them into IMMessage.track and publish. */
+int gpscal_imgps_message(gpscal_ctx *ctx, int method, int band_type, const double *calibrated_xyztw, int n,
+                         double *blw);
 
 /* ------------------------------------------------ scanRegistration, VoxelGrid */
 /* Replaces scanRegistration's laserCloudHandler (SR:238-674, IMU inactive) for nsweeps raw

@@ -74,6 +74,67 @@ def test_driver_kml_matches_oracle(tmp_path):
     assert strip(got1) == strip(ref1)
 
 
+def test_large_demo_like_run_on_the_shipped_gps_log(tmp_path, gps_log_bytes):
+    """BASELINE configs[2] ("large_size_demo_data ... end-to-end, KML diff vs reference") with the substitute SURVEY 8(d)
+    defines: the bags are an external download, so the SLAM segments are derived from the GPRMC log the reference ships
+    (all 2 490 fixes of data/original_gps_data.txt, CRLF lines and blank lines as shipped) -- smoothed, cut at run.sh's
+    1000 / 300 / 100 m, each segment under its own unknown rigid transform (synth.large_demo_like).  gpscal_run ->
+    both KML files against the oracle chain: coordinates within 1e-9 degrees, same structure and colours."""
+    if not os.path.exists(RUN):
+        pytest.fail("gpscal_run is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    gprmc = gps_log_bytes.decode()
+    longs, shorts = synth.large_demo_like(gprmc)
+    assert len(longs) >= 5 and len(shorts) >= 25 and max(len(s) for s in longs) > 2304  # longer than the LDS-resident size
+    trk, log = tmp_path / "tracks.txt", tmp_path / "original_gps_data.txt"
+    synth.write_track_file(str(trk), longs, shorts)
+    log.write_bytes(gps_log_bytes)
+    k0, k1 = tmp_path / "ori.kml", tmp_path / "cal.kml"
+    r = subprocess.run([RUN, "--gps_input_filename", str(log), "--slam_track_filename", str(trk),
+                        "--gps_original_filename", str(k0), "--gps_improved_filename", str(k1),
+                        "--kml_config", "/nonexistent"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    gps, acc = _oracle_run(longs, shorts, gprmc)
+    ll0, alt0 = O.local_to_wgs(gps)
+    ll1, alt1 = O.local_to_wgs(acc)
+    end1, rgb1 = O.colour_segments(acc)
+    ref0, ref1 = O.kml(ll0, alt0, 0), O.kml(ll1, alt1, 1, end1, rgb1)
+    got0, got1 = k0.read_text(), k1.read_text()
+    c0, c1, r0, r1 = _kml_coords(got0), _kml_coords(got1), _kml_coords(ref0), _kml_coords(ref1)
+    assert c0.shape == r0.shape == (len(gps), 3) and len(gps) > 24000
+    assert c1.shape == r1.shape == (len(acc) - 1, 3)
+    assert np.abs(c0 - r0).max() < 1e-9 and np.abs(c1 - r1).max() < 1e-9
+    strip = lambda s: re.sub(r"^-?[\d.]+,-?[\d.]+,-?[\d.]+$", "C", s, flags=re.M)
+    assert strip(got0) == strip(ref0) and strip(got1) == strip(ref1)
+    # sanity of the substitute (not parity): the calibrated track stays inside the area the raw fixes cover
+    assert (c1[:, :2].min(0) > c0[:, :2].min(0) - 1e-3).all() and (c1[:, :2].max(0) < c0[:, :2].max(0) + 1e-3).all()
+
+
+def test_imorpheus_gps_payload_matches_oracle(tmp_path):
+    """result_control 4 (short_distance_track_process.cpp:295-309): IMMessage.track = IMGPS{b, l, w} per calibrated
+    point -- gpscal_imgps_message through the Python binding and through gpscal_run (which, without ROS, writes the
+    records to the "improved" file) against the oracle's inverse projection and merged weights."""
+    from gpscalibration_amd import Context
+    longs, shorts, gprmc = synth.segmented_run(2400, 800, 300, 100, seed=13, dropout=0.1)
+    gps, acc = _oracle_run(longs, shorts, gprmc)
+    ll, _ = O.local_to_wgs(acc)
+    ref = np.c_[ll[:, 1], ll[:, 0], acc[:, 4]]
+    ctx = Context(0)
+    got = ctx.imgps_message(acc)
+    ctx.close()
+    assert got.shape == ref.shape and np.abs(got[:, :2] - ref[:, :2]).max() < 1e-10 and np.array_equal(got[:, 2], ref[:, 2])
+    trk, log, out = tmp_path / "tracks.txt", tmp_path / "gps.txt", tmp_path / "msg.txt"
+    synth.write_track_file(str(trk), longs, shorts)
+    log.write_text(gprmc)
+    r = subprocess.run([RUN, "--gps_input_filename", str(log), "--slam_track_filename", str(trk), "--result_control", "4",
+                        "--gps_original_filename", str(tmp_path / "unused.kml"), "--gps_improved_filename", str(out)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    msg = np.loadtxt(out, delimiter=",")
+    assert msg.shape == ref.shape
+    assert np.abs(msg[:, :2] - ref[:, :2]).max() < 1e-9 and np.abs(msg[:, 2] / ref[:, 2] - 1).max() < 1e-6
+
+
 def test_driver_rejects_bad_arguments(tmp_path):
     r = subprocess.run([RUN, "--gps_input_filename", "x", "--slam_track_filename", "y", "--ctm", "Mercator"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)

@@ -213,3 +213,42 @@ def test_bag_to_kml_orchestration_gloo_world2(tmp_path):
     for ext in (".ori.kml", ".cal.kml"):
         a, b = open(ref + ext, "rb").read(), open(out + ext, "rb").read()
         assert len(a) > 1000 and a == b, ext
+
+
+def test_rosbag_reader_view_semantics_and_malformed_files(tmp_path):
+    """What rosbag::View gives input_data (input_data.cpp:160-190, 305-313) beyond a single in-order topic: the
+    wanted topic published on several connections, foreign topics of other types (and one of the same type)
+    interleaved, chunks stored out of time order -- the reader must return the velodyne_points clouds, all of
+    them, in time order.  And files whose declared layout does not fit their data (field offset beyond
+    point_step, absurd width, absurd chunk size) must be refused with the reader's own error, not crash.
+    (Bags are written by synth.write_rosbag: no real bag exists in this container -- parity unpinned.)"""
+    import struct
+    from gpscalibration_amd import pipeline, synth
+    rng = np.random.default_rng(4)
+    sweeps = [rng.normal(0, 15, (n, 3)).astype(np.float32) for n in (300, 1, 700, 64, 0, 512, 900, 33, 260, 128, 77)]
+    stamps = 1494650700.0 + 0.1 * np.arange(len(sweeps)) + 0.000321
+    imu = struct.pack("<I", 7) + b"x" * 200
+    other_cloud = b"\x00" * 60  # a PointCloud2-typed message of ANOTHER topic must not even be parsed
+    foreign = []
+    for k in range(len(sweeps)):
+        foreign.append(("/imu/data", "sensor_msgs/Imu", stamps[k] + 0.013, imu))
+        if k % 3 == 0:
+            foreign.append(("/velodyne_points_raw", "sensor_msgs/PointCloud2", stamps[k] + 0.031, other_cloud))
+    nchunks = (len(sweeps) + len(foreign) + 4) // 5
+    order = list(rng.permutation(nchunks))
+    assert order != sorted(order)
+    for comp in ("none", "bz2"):
+        path = str(tmp_path / ("view_%s.bag" % comp))
+        synth.write_rosbag(path, sweeps, stamps, chunk_msgs=5, compression=comp, publishers=2, foreign=foreign,
+                           chunk_order=order)
+        got, st = pipeline.read_bag(path, "velodyne_points")
+        assert len(got) == len(sweeps)
+        assert np.all(np.diff(st) > 0) and np.abs(st - stamps).max() < 1e-9
+        for a, b in zip(got, sweeps):
+            assert a.shape == b.shape and np.array_equal(a, b)
+    for bad in ("field_offset", "huge_width", "chunk_size"):
+        path = str(tmp_path / ("bad_%s.bag" % bad))
+        synth.write_rosbag(path, sweeps[:4], stamps[:4], chunk_msgs=3, compression="bz2" if bad == "chunk_size" else "none",
+                           corrupt=bad)
+        with pytest.raises(RuntimeError):
+            pipeline.read_bag(path, "velodyne_points")
