@@ -31,7 +31,8 @@ class GpscalError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libgpscal_hip.so")
+    # GPSCAL_LIB: another build of the library (tuning experiments)
+    return os.environ.get("GPSCAL_LIB") or os.path.join(_HERE, "libgpscal_hip.so")
 
 
 def _strerror(code):

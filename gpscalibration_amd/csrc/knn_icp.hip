@@ -498,10 +498,10 @@ template <bool WEIGHTED>
 __global__ __launch_bounds__(64) void icp_solve_kernel(const PairDesc *__restrict__ pairs,
                                                         const double *__restrict__ partials,
                                                         double *__restrict__ pose64, float *__restrict__ pose32,
-                                                        double *__restrict__ err_hist, int it, int iters_cap)
+                                                        double *__restrict__ err_hist, int it, int iters_cap, int pair0)
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
-    const int b = blockIdx.x;
+    const int b = pair0 + blockIdx.x;
     const PairDesc &P = pairs[b];
     const int lane = threadIdx.x;
     double a[NACC];
@@ -880,8 +880,18 @@ struct gpscal_scan_batch {
     hipGraphExec_t graph = nullptr;
     int graph_iters = 0;
     double build_seconds = 0.0;
+    // independent step -> solve chains of the captured graph (launch_step)
+    static constexpr int MAX_CHAINS = 8;
+    int nchains = 1;
+    int chain_pair[MAX_CHAINS + 1] = {}, chain_blk[MAX_CHAINS + 1] = {};
+    hipStream_t chain_stream[MAX_CHAINS] = {};
+    hipEvent_t chain_ev[MAX_CHAINS] = {};
     ~gpscal_scan_batch()
     {
+        for (int c = 1; c < MAX_CHAINS; ++c) {
+            if (chain_stream[c]) (void)hipStreamDestroy(chain_stream[c]);
+            if (chain_ev[c]) (void)hipEventDestroy(chain_ev[c]);
+        }
         if (graph) (void)hipGraphExecDestroy(graph);
         if (tgt && !borrowed) delete tgt;
     }
@@ -1027,6 +1037,26 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
         P.pblk_cnt = (int)bp.size() - P.pblk_off;
     }
     B->nblk = (int)bp.size();
+    // chains: contiguous groups of pairs with (nearly) equal block counts; small batches keep one
+    {
+        int want = np >= 32 ? 4 : (np >= 8 ? 2 : 1);  // measured at 64 pairs x 65 536 points: 1 / 2 / 4 chains = 671 / 729 / 748 k iterations/s
+        if (const char *e = getenv("GPSCAL_ICP_CHAINS")) want = std::min(std::max(atoi(e), 1), (int)gpscal_scan_batch::MAX_CHAINS);
+        want = std::min(want, std::max(np, 1));
+        B->nchains = want;
+        B->chain_pair[0] = 0;
+        B->chain_blk[0] = 0;
+        int p = 0;
+        for (int c = 1; c <= want; ++c) {
+            const long long target = (long long)B->nblk * c / want;
+            while (p < np && (c == want || B->hpairs[p].pblk_off + B->hpairs[p].pblk_cnt <= target)) ++p;
+            B->chain_pair[c] = c == want ? np : p;
+            B->chain_blk[c] = c == want ? B->nblk : (p < np ? B->hpairs[p].pblk_off : B->nblk);
+        }
+        for (int c = 1; c < want; ++c) {
+            GPSCAL_HIP(ctx, hipStreamCreateWithFlags(&B->chain_stream[c], hipStreamNonBlocking));
+            GPSCAL_HIP(ctx, hipEventCreateWithFlags(&B->chain_ev[c], hipEventDisableTiming));
+        }
+    }
     GPSCAL_HIP(ctx, B->blk_pair.alloc(bp.size()));
     GPSCAL_HIP(ctx, B->blk_first.alloc(bf.size()));
     if (!bp.empty()) {
@@ -1119,16 +1149,22 @@ extern "C" int gpscal_scan_batch_set_pose(gpscal_scan_batch *B, const double *T0
     return GPSCAL_OK;
 }
 
-static void launch_step(gpscal_scan_batch *B, bool last)
+// The pairs of a batch form `nchains` groups (contiguous halves ...), each with its own dependent chain of
+// step -> solve -> step ...: while one group's solve kernel (one wave per pair, ~9 us of dependent float64
+// arithmetic) runs, the other groups' step kernels keep the chip busy.  Chain c = pairs [chain_pair[c],
+// chain_pair[c+1]) = blocks [chain_blk[c], chain_blk[c+1]); partial-sum slots stay global.
+static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st)
 {
-    gpscal_ctx *ctx = B->ctx;
     GridSet &G = *B->tgt;
-    if (B->nblk == 0) return;
-#define STEP(QPT, W, BALL)                                                                                   \
-    hipLaunchKernelGGL((icp_step_kernel<QPT, W, BALL>), dim3(B->nblk), dim3(BLOCK), 0, ctx->stream, B->pairs.p, \
-                       B->blk_pair.p, B->blk_first.p, B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p,  \
-                       G.cell_start, B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p,        \
-                       B->partials.p, B->nblk, (B->diag & 0xff) | (B->ball_r << 8), last ? 1 : 0)
+    // c < 0: the whole batch in one launch (profiling mode: the launch the roofline is quoted for)
+    const int b0 = c < 0 ? 0 : B->chain_blk[c], nb = (c < 0 ? B->nblk : B->chain_blk[c + 1]) - b0;
+    if (nb <= 0) return;
+#define STEP(QPT, W, BALL)                                                                                        \
+    hipLaunchKernelGGL((icp_step_kernel<QPT, W, BALL>), dim3(nb), dim3(BLOCK), 0, st, B->pairs.p, B->blk_pair.p + b0, \
+                       B->blk_first.p + b0, B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p, G.cell_start,   \
+                       B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p,                              \
+                       B->partials.p + (size_t)b0 * (B->weighted ? NACC_WEIGHTED : NACC_PLAIN), nb,                  \
+                       (B->diag & 0xff) | (B->ball_r << 8), last ? 1 : 0)
     // the ball search costs the kernel a wave of occupancy: its own instantiation, chosen per batch
     const bool ball = B->ball_r > 0;
     if (B->weighted) {
@@ -1139,15 +1175,16 @@ static void launch_step(gpscal_scan_batch *B, bool last)
 #undef STEP
 }
 
-static void launch_solve(gpscal_scan_batch *B, int it)
+static void launch_solve(gpscal_scan_batch *B, int it, int c, hipStream_t st)
 {
-    gpscal_ctx *ctx = B->ctx;
+    const int p0 = c < 0 ? 0 : B->chain_pair[c], np = (c < 0 ? B->npairs : B->chain_pair[c + 1]) - p0;
+    if (np <= 0) return;
     if (B->weighted)
-        hipLaunchKernelGGL(icp_solve_kernel<true>, dim3(B->npairs), dim3(64), 0, ctx->stream, B->pairs.p,
-                           B->partials.p, B->pose64.p, B->pose32.p, B->err_hist.p, it, B->err_cap);
+        hipLaunchKernelGGL(icp_solve_kernel<true>, dim3(np), dim3(64), 0, st, B->pairs.p, B->partials.p, B->pose64.p,
+                           B->pose32.p, B->err_hist.p, it, B->err_cap, p0);
     else
-        hipLaunchKernelGGL(icp_solve_kernel<false>, dim3(B->npairs), dim3(64), 0, ctx->stream, B->pairs.p,
-                           B->partials.p, B->pose64.p, B->pose32.p, B->err_hist.p, it, B->err_cap);
+        hipLaunchKernelGGL(icp_solve_kernel<false>, dim3(np), dim3(64), 0, st, B->pairs.p, B->partials.p, B->pose64.p,
+                           B->pose32.p, B->err_hist.p, it, B->err_cap, p0);
 }
 
 extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_out, double *mean_err,
@@ -1171,9 +1208,9 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
         for (auto &e : ev) GPSCAL_HIP(ctx, hipEventCreate(&e));
         for (int it = 0; it < iters; ++it) {
             GPSCAL_HIP(ctx, hipEventRecord(ev[2 * it], ctx->stream));
-            launch_step(B, it == iters - 1);
+            launch_step(B, it == iters - 1, -1, ctx->stream);
             GPSCAL_HIP(ctx, hipEventRecord(ev[2 * it + 1], ctx->stream));
-            launch_solve(B, it);
+            launch_solve(B, it, -1, ctx->stream);
         }
         GPSCAL_HIP(ctx, hipGetLastError());
         GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1186,10 +1223,21 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
                 B->graph = nullptr;
             }
             hipGraph_t g = nullptr;
+            // chain 0 on the context's stream, the others on side streams forked from / joined to it
             GPSCAL_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-            for (int it = 0; it < iters; ++it) {
-                launch_step(B, it == iters - 1);
-                launch_solve(B, it);
+            for (int c = 1; c < B->nchains; ++c) {
+                GPSCAL_HIP(ctx, hipEventRecord(B->chain_ev[c], ctx->stream));
+                GPSCAL_HIP(ctx, hipStreamWaitEvent(B->chain_stream[c], B->chain_ev[c], 0));
+            }
+            for (int it = 0; it < iters; ++it)
+                for (int c = 0; c < B->nchains; ++c) {
+                    hipStream_t st = c == 0 ? ctx->stream : B->chain_stream[c];
+                    launch_step(B, it == iters - 1, c, st);
+                    launch_solve(B, it, c, st);
+                }
+            for (int c = 1; c < B->nchains; ++c) {
+                GPSCAL_HIP(ctx, hipEventRecord(B->chain_ev[c], B->chain_stream[c]));
+                GPSCAL_HIP(ctx, hipStreamWaitEvent(ctx->stream, B->chain_ev[c], 0));
             }
             GPSCAL_HIP(ctx, hipStreamEndCapture(ctx->stream, &g));
             GPSCAL_HIP(ctx, hipGraphInstantiate(&B->graph, g, nullptr, nullptr, 0));
