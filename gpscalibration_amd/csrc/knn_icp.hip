@@ -347,8 +347,17 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
 // An LDS-staged variant of level 0 (workgroup box of cells copied to LDS) was built
 // and measured SLOWER than this pruned global path (the box holds ~3.3 points per
 // query against ~2.4 the query reads); see DESIGN.md.
+// Queries per workgroup of the step kernel.  Smaller workgroups give wave slots and LDS back sooner (a workgroup
+// retires with its slowest wave: in the search-heavy iterations the waves of one workgroup differ a lot); with
+// single-wave workgroups the kernel itself is fastest (launch times 346 ... 47 us against 385 ... 49 us for 256
+// threads) but four concurrent chains of 16 384-workgroup launches then cost more than they hide.
+#ifndef GPSCAL_STEP_BLOCK
+#define GPSCAL_STEP_BLOCK 128  // measured at 64 x 65 536 points, 4 chains: 64 / 128 / 256 threads = 728 / 775 / 746 k iterations/s
+#endif
+constexpr int STEP_BLOCK = GPSCAL_STEP_BLOCK;
+
 template <int QPT, bool WEIGHTED, bool BALL>
-__global__ __launch_bounds__(BLOCK) void icp_step_kernel(
+__global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
     const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
     const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
     const float4 *__restrict__ nbr, const float2 *__restrict__ pt_r2, const unsigned *__restrict__ cell_start,
@@ -357,8 +366,8 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
     int write_nn)
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
-    __shared__ double wsum[BLOCK / 64][NACC];
-    __shared__ double tslab[BLOCK / 64][8][64];  // per-wave transpose slab (16 KiB / block)
+    __shared__ double wsum[STEP_BLOCK / 64][NACC];
+    __shared__ double tslab[STEP_BLOCK / 64][8][64];  // per-wave transpose slab (4 KiB / wave)
 
     const int lb = xcd_remap(blockIdx.x, nblk);
     const int b = __builtin_amdgcn_readfirstlane(blk_pair[lb]);
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
 
 #pragma unroll 1
     for (int q = 0; q < QPT; ++q) {
-        const int i = first + q * BLOCK + (int)threadIdx.x;
+        const int i = first + q * STEP_BLOCK + (int)threadIdx.x;
         const bool valid = i < P.n;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 wq = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(BLOCK) void icp_step_kernel(
     if (threadIdx.x < NACC) {
         double v = 0.0;
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; ++w) v += wsum[w][threadIdx.x];
+        for (int w = 0; w < STEP_BLOCK / 64; ++w) v += wsum[w][threadIdx.x];
         partials[(size_t)lb * NACC + threadIdx.x] = v;
     }
 }
@@ -1029,7 +1038,7 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
     for (int b = 0; b < np; ++b) {
         PairDesc &P = B->hpairs[b];
         P.pblk_off = (int)bp.size();
-        int per = BLOCK * B->qpt;
+        int per = STEP_BLOCK * B->qpt;
         for (int f = 0; f < P.n; f += per) {
             bp.push_back(b);
             bf.push_back(f);
@@ -1160,7 +1169,7 @@ static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st)
     const int b0 = c < 0 ? 0 : B->chain_blk[c], nb = (c < 0 ? B->nblk : B->chain_blk[c + 1]) - b0;
     if (nb <= 0) return;
 #define STEP(QPT, W, BALL)                                                                                        \
-    hipLaunchKernelGGL((icp_step_kernel<QPT, W, BALL>), dim3(nb), dim3(BLOCK), 0, st, B->pairs.p, B->blk_pair.p + b0, \
+    hipLaunchKernelGGL((icp_step_kernel<QPT, W, BALL>), dim3(nb), dim3(STEP_BLOCK), 0, st, B->pairs.p, B->blk_pair.p + b0, \
                        B->blk_first.p + b0, B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p, G.cell_start,   \
                        B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p,                              \
                        B->partials.p + (size_t)b0 * (B->weighted ? NACC_WEIGHTED : NACC_PLAIN), nb,                  \

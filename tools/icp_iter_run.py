@@ -1,11 +1,14 @@
-"""Runs N ICP iterations on the benchmark batch (for per-dispatch rocprofv3 --pmc passes)."""
+"""Runs N ICP iterations on the benchmark batch as whole-batch launches of icp_step_kernel (profiling mode of
+gpscal_scan_batch_icp: the launch the bench's roofline is quoted for), for per-dispatch rocprofv3 --pmc passes."""
+import os
 import sys
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch
 from gpscalibration_amd import Context, synth
-npairs, n, iters = 64, 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 12
+npairs, n, iters = 64, 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 50
 tg, to, sr, so, _ = synth.scan_batch(npairs, n)
 ctx = Context(0)
 sb = ctx.scan_batch(torch.from_numpy(tg).cuda(), to, torch.from_numpy(sr).cuda(), so)
-sb.icp(iters, want_err=False)
+sb.icp(iters, want_err=False, profile=True)
 ctx.sync()

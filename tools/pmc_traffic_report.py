@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
-"""Average FETCH_SIZE / WRITE_SIZE per launch of one kernel -> HBM bytes per launch.
+"""FETCH_SIZE / WRITE_SIZE of icp_step_kernel per launch and per iteration -> HBM bytes.
 
-gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B
-fabric request, i.e. exactly half the bytes of wide coalesced reads -> doubled here;
-WRITE_SIZE is exact.  Both counters are in KiB."""
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B fabric request, i.e.
+exactly half the bytes of wide coalesced reads -> doubled here; WRITE_SIZE is exact.  Both counters are in KiB.
+Usage: pmc_traffic_report.py <outdir with FETCH_SIZE/ and WRITE_SIZE/ passes> <grid size in threads> <key> <note>"""
 import csv
 import glob
 import json
+import os
 import sys
 
-outdir, kern, key = sys.argv[1], sys.argv[2], sys.argv[3]
-res = {}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_sha16  # noqa: E402
+
+outdir, grid, key, note = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+per = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = []
     for f in glob.glob("%s/%s/*/*counter_collection.csv" % (outdir, c)):
-        for r in csv.DictReader(open(f)):
-            if kern in r["Kernel_Name"] and r["Counter_Name"] == c and r["Grid_Size"] == sys.argv[4]:
-                vals.append(float(r["Counter_Value"]))
-    res[c] = (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
-f, w = res["FETCH_SIZE"][0], res["WRITE_SIZE"][0]
-rec = {"FETCH_SIZE_KiB_avg": f, "WRITE_SIZE_KiB_avg": w, "launches": res["FETCH_SIZE"][1],
-       "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 if f is not None and w is not None else None,
-       "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE x1"}
+        rows = [r for r in csv.DictReader(open(f))
+                if "icp_step_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c and r["Grid_Size"] == grid]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        vals = [float(r["Counter_Value"]) for r in rows]
+    per[c] = vals
+n = min(len(per["FETCH_SIZE"]), len(per["WRITE_SIZE"]))
+by_it = [(2.0 * per["FETCH_SIZE"][i] + per["WRITE_SIZE"][i]) * 1024.0 for i in range(n)]
+rec = {"FETCH_SIZE_KiB_avg": sum(per["FETCH_SIZE"][:n]) / n, "WRITE_SIZE_KiB_avg": sum(per["WRITE_SIZE"][:n]) / n,
+       "launches": n, "hbm_bytes_per_launch": sum(by_it) / n, "hbm_bytes_by_iteration": by_it,
+       "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE x1",
+       "kernel_source_sha16": kernel_source_sha16(), "collected": note}
 print(json.dumps({key: rec}, indent=1))

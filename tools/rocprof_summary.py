@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Summary of a rocprofv3 --kernel-trace of bench.py: icp_step_kernel launches by grid size (whole-batch launches of
+the roofline measurement, per-chain launches of the timed region), the solve kernel, and the agreement with the
+bench's own HIP-event numbers.  Usage: rocprof_summary.py <trace dir> <bench json>"""
+import csv
+import glob
+import json
+import sys
+
+f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+bench = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
+rows = list(csv.DictReader(open(f)))
+d = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+out = {"bench_roofline": bench["roofline"], "bench_value": bench["value"], "bench_ms_per_step": bench["ms_per_step"]}
+groups = {}
+for r in rows:
+    name = r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]
+    if name in ("icp_step_kernel", "icp_solve_kernel"):
+        groups.setdefault((name, int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"])), []).append(d(r))
+out["kernels"] = [{"kernel": k[0], "grid_threads": k[1], "launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v),
+                   "max_us": max(v), "vgpr": None} for k, v in sorted(groups.items())]
+whole = [g for g in out["kernels"] if g["kernel"] == "icp_step_kernel" and g["grid_threads"] == bench["config"]["pairs_per_gpu"] * bench["config"]["points"]]
+if whole:
+    out["whole_batch_avg_us_rocprof"] = whole[0]["avg_us"]
+    out["whole_batch_avg_us_bench_events"] = 1e3 * bench["roofline"]["avg_launch_ms"]
+    out["roofline_frac_from_rocprof"] = bench["roofline"]["algorithmic_bytes_per_launch"] / (whole[0]["avg_us"] * 1e-6) / 8e12
+print(json.dumps(out, indent=1))
