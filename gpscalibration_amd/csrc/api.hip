@@ -62,6 +62,10 @@ extern "C" int gpscal_destroy(gpscal_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->comm) (void)gpscal_comm_destroy(ctx);
     if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
+    for (int k = 0; k < gpscal_ctx::MAX_SIDE; ++k) {
+        if (ctx->side_stream[k]) (void)hipStreamDestroy(ctx->side_stream[k]);
+        if (ctx->side_event[k]) (void)hipEventDestroy(ctx->side_event[k]);
+    }
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
         cache_trim(ctx->stream);  // the stream's cached temporaries go back to the driver

@@ -21,6 +21,10 @@ struct gpscal_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t order_event = nullptr;  // gpscal_wait_for_stream / gpscal_make_stream_wait
+    // side streams of the ICP graph's independent chains (created on first use, shared by every scan batch)
+    static constexpr int MAX_SIDE = 8;
+    hipStream_t side_stream[MAX_SIDE] = {};
+    hipEvent_t side_event[MAX_SIDE] = {};
     hipDeviceProp_t prop{};
     std::string last_error;
     void *comm = nullptr;  // ncclComm_t, owned by comm.hip

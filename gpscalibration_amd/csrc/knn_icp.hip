@@ -893,14 +893,10 @@ struct gpscal_scan_batch {
     static constexpr int MAX_CHAINS = 8;
     int nchains = 1;
     int chain_pair[MAX_CHAINS + 1] = {}, chain_blk[MAX_CHAINS + 1] = {};
-    hipStream_t chain_stream[MAX_CHAINS] = {};
+    hipStream_t chain_stream[MAX_CHAINS] = {};  // the context's side streams (not owned)
     hipEvent_t chain_ev[MAX_CHAINS] = {};
     ~gpscal_scan_batch()
     {
-        for (int c = 1; c < MAX_CHAINS; ++c) {
-            if (chain_stream[c]) (void)hipStreamDestroy(chain_stream[c]);
-            if (chain_ev[c]) (void)hipEventDestroy(chain_ev[c]);
-        }
         if (graph) (void)hipGraphExecDestroy(graph);
         if (tgt && !borrowed) delete tgt;
     }
@@ -1061,9 +1057,12 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
             B->chain_pair[c] = c == want ? np : p;
             B->chain_blk[c] = c == want ? B->nblk : (p < np ? B->hpairs[p].pblk_off : B->nblk);
         }
-        for (int c = 1; c < want; ++c) {
-            GPSCAL_HIP(ctx, hipStreamCreateWithFlags(&B->chain_stream[c], hipStreamNonBlocking));
-            GPSCAL_HIP(ctx, hipEventCreateWithFlags(&B->chain_ev[c], hipEventDisableTiming));
+        static_assert(gpscal_scan_batch::MAX_CHAINS <= gpscal_ctx::MAX_SIDE, "side streams");
+        for (int c = 1; c < want; ++c) {  // the context's side streams: created once, on first use
+            if (!ctx->side_stream[c]) GPSCAL_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream[c], hipStreamNonBlocking));
+            if (!ctx->side_event[c]) GPSCAL_HIP(ctx, hipEventCreateWithFlags(&ctx->side_event[c], hipEventDisableTiming));
+            B->chain_stream[c] = ctx->side_stream[c];
+            B->chain_ev[c] = ctx->side_event[c];
         }
     }
     GPSCAL_HIP(ctx, B->blk_pair.alloc(bp.size()));
