@@ -138,3 +138,47 @@ def test_rccl_allgather_chains_ragged_path_world_of_one(monkeypatch):
         ctx._ck(ctx._L.gpscal_allgather_chains(ctx._h, None, _ptr(cnt), _ptr(d_out)), "allgather null")
     ctx.comm_destroy()
     ctx.close()
+
+
+_COEXIST = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["GPSCAL_ROOT"])
+from gpscalibration_amd import Context
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+t = torch.ones(4, device="cuda")
+dist.all_reduce(t)                       # torch's RCCL communicator is live
+ctx = Context(0)
+uid = [Context.comm_unique_id()]
+dist.broadcast_object_list(uid, src=0)   # the way bench.py hands the id around
+ctx.comm_init(uid[0], 0, 1)
+x = np.arange(4096, dtype=np.float64)
+assert np.array_equal(ctx.allgather_chains(x, [4096]), x)
+d_in = torch.arange(64 * 16, dtype=torch.float64, device="cuda")
+d_out = torch.empty_like(d_in)
+from gpscalibration_amd.api import _ptr
+cnt = np.array([64 * 16], dtype=np.int32)
+for _ in range(3):
+    ctx._ck(ctx._L.gpscal_allgather_chains(ctx._h, _ptr(d_in), _ptr(cnt), _ptr(d_out)), "gather")
+    dist.all_reduce(t)                   # interleaved with torch's collectives
+assert torch.equal(d_in, d_out)
+ctx.comm_destroy(); ctx.close()
+dist.barrier(); dist.destroy_process_group()
+print("coexist ok")
+'''
+
+
+def test_library_rccl_communicator_next_to_torch_distributed(tmp_path):
+    """bench.py --gpus N creates the library's RCCL communicator (gpscal_comm_init, librccl dlopen'ed by the library)
+    inside a process whose torch.distributed NCCL backend is already up, and interleaves both.  One rank, one GPU:
+    what can be checked here is that the two coexist and that the id travels through broadcast_object_list."""
+    script = tmp_path / "coexist.py"
+    script.write_text(_COEXIST)
+    env = dict(os.environ, GPSCAL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "coexist ok" in r.stdout, r.stdout[-3000:]
