@@ -199,22 +199,26 @@ def large_demo_bench(tmpdir):
             "note": "track path only: the bags of large_size_demo_data are an external download (README.md:65-66)"}
 
 
-def loam_chain_bench(ctx, nseg=6, nsweeps=30, n_az=1800):
+def loam_chain_bench(ctx, nseg=6, nsweeps=30, n_az=1800, cpu=True):
     """The LOAM node chain ahead of the track path: raw 16-ring sweeps of
     `nseg` synthetic drives -> /true_odometry_to_init samples, all segments in lock step on the GPU;
     next to it the single-thread CPU restatement on one of the segments."""
     import _oracle as O
     from gpscalibration_amd import synth
-    W = synth.lidar_world(0, length=600.0)
+    W = synth.lidar_world(0, length=max(600.0, 20.0 * nseg + 300.0))
     segs, stamps = [], []
     for sgm in range(nseg):
-        sw, st, _ = synth.drive(W, nsweeps, seed=100 + sgm, n_az=n_az, start=(20.0 * sgm, 0.3 * sgm))
+        sw, st, _ = synth.drive(W, nsweeps, seed=100 + sgm, n_az=n_az, start=(20.0 * sgm, 0.3 * (sgm % 8)))
         segs.append(sw)
         stamps.append(st)
     ctx.loam_run([segs[0][:4]], [stamps[0][:4]])  # warm-up
     t0 = time.perf_counter()
     got = ctx.loam_run(segs, stamps)
     dt = time.perf_counter() - t0
+    if not cpu:
+        return {"segments": nseg, "sweeps_per_segment": nsweeps, "points_per_sweep": int(len(segs[0][0])),
+                "gpu_seconds": dt, "gpu_sweeps_per_s": nseg * nsweeps / dt,
+                "note": "host->device copy of the raw sweeps included; segments advance in lock step"}
     t0 = time.perf_counter()
     ref = O.loam_run(segs[0], stamps[0])
     dc = time.perf_counter() - t0
@@ -477,6 +481,10 @@ def main():
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(n, args.iters)
         if world == 1 and not args.no_loam:
             out["loam_chain"] = loam_chain_bench(ctx)
+            # the design point of the chain is many segments in flight (BASELINE configs[3]: 1000 segments over 8 GPUs
+            # = 125 per GPU); 6 segments (above, as in round 1) leave most of the chip idle
+            big = loam_chain_bench(ctx, nseg=48, nsweeps=20, cpu=False)
+            out["loam_chain_48_segments"] = big
         if world == 1 and not args.no_track:
             import tempfile
             with tempfile.TemporaryDirectory() as td:
