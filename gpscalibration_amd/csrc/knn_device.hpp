@@ -32,6 +32,28 @@ struct PairDesc {
     GridDesc lv[MAX_LEVELS];
 };
 
+// Search statistics (tools/search_stats.py; -DGPSCAL_STATS builds only): counters per ICP iteration,
+// NSTAT per iteration, read back through gpscal_debug_stats.
+#ifdef GPSCAL_STATS
+constexpr int NSTAT = 24, STAT_ITERS = 64;
+static __device__ unsigned long long g_stats[NSTAT * STAT_ITERS];
+static __device__ int g_stat_iter;
+#define STAT_ADD(k, v) atomicAdd(&g_stats[g_stat_iter * NSTAT + (k)], (unsigned long long)(v))
+#define STAT_WAVE(k, v)                                      \
+    do {                                                     \
+        const unsigned long long v_ = (v);                   \
+        if ((threadIdx.x & 63) == 0) STAT_ADD(k, v_);        \
+    } while (0)
+__device__ __forceinline__ unsigned stat_wave_max(unsigned v)
+{
+    for (int o = 32; o; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+    return v;
+}
+#else
+#define STAT_ADD(k, v) ((void)0)
+#define STAT_WAVE(k, v) ((void)0)
+#endif
+
 // ------------------------------------------------------------------ helpers
 
 __device__ __forceinline__ int f2ord(float f)
@@ -216,6 +238,15 @@ template <class BT>
 __device__ __forceinline__ void scan_short(BT &B, bool act, const float4 *__restrict__ sorted, unsigned s, unsigned e,
                                            float px, float py, float pz)
 {
+#ifdef GPSCAL_STATS
+    {
+        const unsigned len = act ? e - s : 0u, trips = (len + 3) / 4;
+        const unsigned wt = stat_wave_max(trips);
+        STAT_WAVE(7, wt);             // wave-level groups of four
+        STAT_ADD(8, len);             // lane-level candidates
+        STAT_ADD(16, trips);          // lane-level groups of four
+    }
+#endif
     if (!act) return;
     unsigned j = s;
     // full groups of four: no clamps, no per-candidate guards
@@ -269,6 +300,8 @@ __device__ __forceinline__ void scan_runs(BT &B, bool act, const float4 *__restr
             m &= m - 1;
             const float qx = readlane_f(px, owner), qy = readlane_f(py, owner), qz = readlane_f(pz, owner);
             const unsigned ss = __builtin_amdgcn_readlane(s, owner), ee = __builtin_amdgcn_readlane(e, owner);
+            STAT_WAVE(9, 1);
+            STAT_WAVE(10, ee - ss);
             float bd = INFINITY;
             int bi = 0x7fffffff;
             unsigned bp = 0;
@@ -380,6 +413,8 @@ __device__ __forceinline__ void block3_level(const GridDesc &G, const CellGeo &C
         const float rb2 = (ky == 0 ? 0.f : (ky == 1 ? by2[1] : by2[2])) + (kz == 0 ? 0.f : (kz == 1 ? bz2[1] : bz2[2]));
         const bool pass = ((lanemask >> r) & 1u) && rb2 * 0.99999f <= B.worst();
         if (__ballot(pass) == 0ull) continue;  // an earlier row tightened the bound
+        STAT_WAVE(5, 1);
+        STAT_WAVE(6, __popcll(__ballot(pass)));
         const unsigned c0 = has_l ? q.a : q.b, c1 = q.b, c2 = q.c, c3 = has_r ? q.d : q.c;
         // left | own | right cells are one contiguous run: cells whose face is already
         // within reach are scanned together with the own cell (one pass of loads instead
@@ -388,6 +423,118 @@ __device__ __forceinline__ void block3_level(const GridDesc &G, const CellGeo &C
         const bool pl0 = pass && c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst();
         const bool pr0 = pass && c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst();
         scan_runs(B, pass, sorted, pl0 ? c0 : c1, pr0 ? c3 : c2, px, py, pz);
+    }
+}
+
+// The same level search with the rows after the own one FLATTENED: a lane needs ~3 of the 9 rows and which
+// ones differs from lane to lane, so visiting the rows one after the other costs the wave the sum over rows of
+// the longest run in each (measured at 64 x 65 536 points: 17-20 groups of four per wave against 7-8 per lane).
+// Here the own row is scanned first (it tightens the bound), then every lane lists the candidate runs of its
+// remaining rows in a wave-private LDS slab (8 x 64 uint2: the cell boundaries of four rows are in flight
+// together) and walks its own list in groups of four: the wave pays the longest LIST, and the loads of
+// different rows overlap.  Runs long enough for the cooperative scan are still handed to the whole wave.
+// Candidates may be evaluated twice (a clamped group): the (d2, index) key makes that idempotent.
+#ifndef GPSCAL_FLAT_BATCH
+#define GPSCAL_FLAT_BATCH 4
+#endif
+constexpr int FLAT_BATCH = GPSCAL_FLAT_BATCH;  // rows whose cell boundaries are in flight together (1, 2, 4 or 8)
+template <class BT>
+__device__ __forceinline__ void block3_level_flat(const GridDesc &G, const CellGeo &C,
+                                                  const float4 *__restrict__ sorted,
+                                                  const unsigned *__restrict__ cell_start, bool act, float px,
+                                                  float py, float pz, BT &B, uint2 *__restrict__ slab)
+{
+    const float mg = G.margin;
+    const float bxl = fmaxf(C.fx0 - mg, 0.f), bxr = fmaxf(C.fx1 - mg, 0.f);
+    const float bxl2 = bxl * bxl, bxr2 = bxr * bxr;
+    const bool has_l = C.cx > 0, has_r = C.cx + 1 < G.nx;
+    const float by2[3] = {0.f, fmaxf(C.fy0 - mg, 0.f) * fmaxf(C.fy0 - mg, 0.f),
+                          fmaxf(C.fy1 - mg, 0.f) * fmaxf(C.fy1 - mg, 0.f)};
+    const float bz2[3] = {0.f, fmaxf(C.fz0 - mg, 0.f) * fmaxf(C.fz0 - mg, 0.f),
+                          fmaxf(C.fz1 - mg, 0.f) * fmaxf(C.fz1 - mg, 0.f)};
+    const bool yok[3] = {true, C.cy > 0, C.cy + 1 < G.ny};
+    const bool zok[3] = {true, C.cz > 0, C.cz + 1 < G.nz};
+    const int lane = threadIdx.x & 63;
+    const long long own = G.cell_base + ((long long)C.cz * G.ny + C.cy) * G.nx + C.cx;
+    const long long dyo = G.nx, dzo = (long long)G.ny * G.nx;
+    {  // the own row
+        CellQuad q = {0u, 0u, 0u, 0u};
+        if (act) q = *reinterpret_cast<const CellQuad *>(cell_start + own - 1);
+        const unsigned c0 = has_l ? q.a : q.b, c1 = q.b, c2 = q.c, c3 = has_r ? q.d : q.c;
+        const bool pl0 = act && c0 < c1 && bxl2 * 0.99999f <= B.worst();
+        const bool pr0 = act && c2 < c3 && bxr2 * 0.99999f <= B.worst();
+        STAT_WAVE(5, 1);
+        scan_runs(B, act, sorted, pl0 ? c0 : c1, pr0 ? c3 : c2, px, py, pz);
+    }
+    unsigned cnt = 0;
+#pragma unroll
+    for (int half = 0; half < 8 / FLAT_BATCH; ++half) {
+        CellQuad q[FLAT_BATCH];
+        bool p[FLAT_BATCH];
+#pragma unroll
+        for (int t = 0; t < FLAT_BATCH; ++t) {
+            const int r = 1 + half * FLAT_BATCH + t, kz = r / 3, ky = r - 3 * kz;
+            p[t] = act && yok[ky] && zok[kz] && (by2[ky] + bz2[kz]) * 0.99999f <= B.worst();
+            q[t] = CellQuad{0u, 0u, 0u, 0u};
+            if (p[t]) {
+                const long long row = own + (ky == 0 ? 0 : (ky == 1 ? -dyo : dyo)) + (kz == 0 ? 0 : (kz == 1 ? -dzo : dzo));
+                q[t] = *reinterpret_cast<const CellQuad *>(cell_start + row - 1);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < FLAT_BATCH; ++t) {
+            const int r = 1 + half * FLAT_BATCH + t, kz = r / 3, ky = r - 3 * kz;
+            const float rb2 = by2[ky] + bz2[kz];
+            const unsigned c0 = has_l ? q[t].a : q[t].b, c1 = q[t].b, c2 = q[t].c, c3 = has_r ? q[t].d : q[t].c;
+            const bool pass = p[t] && rb2 * 0.99999f <= B.worst();
+            const bool pl0 = pass && c0 < c1 && (rb2 + bxl2) * 0.99999f <= B.worst();
+            const bool pr0 = pass && c2 < c3 && (rb2 + bxr2) * 0.99999f <= B.worst();
+            const unsigned s = pl0 ? c0 : c1, e = pr0 ? c3 : c2;
+            const bool some = pass && e > s;
+            const bool lng = BT::COOP && some && (e - s) > COOP_MIN;
+            if (some && !lng) {
+                slab[cnt * 64 + lane] = make_uint2(s, e);
+                ++cnt;
+            }
+            if (BT::COOP && __ballot(lng) != 0ull) scan_runs(B, lng, sorted, s, e, px, py, pz);
+        }
+    }
+    // every lane walks its own list; the next entry is fetched while the current run is scanned
+    unsigned j = 0u, e = 0u, k = 2u;
+    uint2 nx = make_uint2(0u, 0u);
+    if (cnt > 0u) {
+        const uint2 r0 = slab[lane];
+        j = r0.x;
+        e = r0.y;
+    }
+    if (cnt > 1u) nx = slab[64 + lane];
+#ifdef GPSCAL_STATS
+    {
+        unsigned g = 0;
+        for (unsigned t = 0; t < cnt; ++t) g += (slab[t * 64 + lane].y - slab[t * 64 + lane].x + 3) / 4;
+        STAT_ADD(19, g);
+        STAT_ADD(20, cnt);
+    }
+#endif
+    while (__ballot(j < e) != 0ull) {
+        STAT_WAVE(18, 1);
+        if (j < e) {
+            const unsigned last = e - 1u;
+            const unsigned j1 = min(j + 1u, last), j2 = min(j + 2u, last), j3 = min(j + 3u, last);
+            const float4 c0 = sorted[j], c1 = sorted[j1], c2 = sorted[j2], c3 = sorted[j3];
+            B.consider(sqdist(px, py, pz, c0.x, c0.y, c0.z), c0, j);
+            B.consider(sqdist(px, py, pz, c1.x, c1.y, c1.z), c1, j1);
+            B.consider(sqdist(px, py, pz, c2.x, c2.y, c2.z), c2, j2);
+            B.consider(sqdist(px, py, pz, c3.x, c3.y, c3.z), c3, j3);
+            j += 4u;
+            if (j >= e) {
+                j = nx.x;
+                e = nx.y;
+                nx = make_uint2(0u, 0u);
+                if (k < cnt) nx = slab[k * 64 + lane];
+                ++k;
+            }
+        }
     }
 }
 
@@ -448,10 +595,10 @@ __device__ __forceinline__ void ball_level(const GridDesc &G, const CellGeo &C, 
 // cells 2.5x .. R x 2.5x smaller than the level the 3x3x3 rule needs, i.e. fewer candidates under
 // the ball when the query is far from the surface the points sample.  Queries without a
 // candidate first climb the 3x3x3 blocks until they hold one.
-template <class BT, bool ALLOW_BALL = false>
+template <class BT, bool ALLOW_BALL = false, bool FLAT = false>
 __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__restrict__ sorted,
                                           const unsigned *__restrict__ cell_start, bool act, float px, float py,
-                                          float pz, BT &B, int ball_r = 0)
+                                          float pz, BT &B, int ball_r = 0, uint2 *__restrict__ slab = nullptr)
 {
     if (!act) px = py = pz = 0.f;
     const bool ballmode = ALLOW_BALL && BT::BALL && ball_r > 0;
@@ -496,8 +643,14 @@ __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__res
             // (prefetched rows); the top level has <= 2 cells per axis, so the block is the whole level
             const float g1 = G.h * 0.999f - G.margin;
             const bool far = pass == 1 && l != P.nlevels - 1 && !(g1 > 0.f && B.worst() <= g1 * g1);
+            STAT_WAVE(3, 1);
+            STAT_WAVE(4, __popcll(__ballot(a)));
+            STAT_WAVE(11 + min(l, 4), __popcll(__ballot(a)));
             if (!ALLOW_BALL || __ballot(a && far) == 0ull) {
-                block3_level(G, C, sorted, cell_start, a, px, py, pz, B);
+                if constexpr (FLAT)
+                    block3_level_flat(G, C, sorted, cell_start, a, px, py, pz, B, slab);
+                else
+                    block3_level(G, C, sorted, cell_start, a, px, py, pz, B);
             } else {
                 ball_level(G, C, sorted, cell_start, a, px, py, pz, B, ball_r);
             }

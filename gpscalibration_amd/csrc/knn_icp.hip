@@ -355,6 +355,9 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
 #define GPSCAL_STEP_BLOCK 128  // measured at 64 x 65 536 points, 4 chains: 64 / 128 / 256 threads = 728 / 775 / 746 k iterations/s
 #endif
 constexpr int STEP_BLOCK = GPSCAL_STEP_BLOCK;
+#ifndef GPSCAL_FLAT_ROWS
+#define GPSCAL_FLAT_ROWS 1  // block3_level_flat: the rows after the own one walked as one list per lane
+#endif
 
 template <int QPT, bool WEIGHTED, bool BALL>
 __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
@@ -423,7 +426,14 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
             }
         }
         if (diag & 1) need = false;
-        knn_query<BestQ, BALL>(P, sorted, cell_start, need, px, py, pz, B, diag >> 8);
+#ifdef GPSCAL_STATS
+        STAT_WAVE(0, __popcll(__ballot(valid)));
+        STAT_WAVE(1, __popcll(__ballot(need)));
+        STAT_WAVE(2, __ballot(need) != 0ull ? 1 : 0);
+        STAT_WAVE(17, __popcll(__ballot(ok && !need && B.pos != BestQ::WARM)));  // settled by tier 2 with a new neighbour
+#endif
+        knn_query<BestQ, BALL, GPSCAL_FLAT_ROWS != 0>(P, sorted, cell_start, need, px, py, pz, B, (diag >> 8) & 0xff,
+                                                     reinterpret_cast<uint2 *>(&tslab[wave][0][0]));
         if (!valid) continue;
         ok = ok && B.index() != 0x7fffffff;
         if (ok && B.pos != BestQ::WARM) {
@@ -1157,6 +1167,20 @@ extern "C" int gpscal_scan_batch_set_pose(gpscal_scan_batch *B, const double *T0
     return GPSCAL_OK;
 }
 
+#ifdef GPSCAL_STATS
+__global__ void stat_set_iter_kernel(int it) { g_stat_iter = it; }
+// instrumented builds only (tools/search_stats.py): the counters of every iteration, then cleared
+extern "C" int gpscal_debug_stats(unsigned long long *out, int n)
+{
+    std::vector<unsigned long long> h(NSTAT * STAT_ITERS, 0ull);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stats), h.size() * 8) != hipSuccess) return GPSCAL_EHIP;
+    for (int i = 0; i < n && i < (int)h.size(); ++i) out[i] = h[i];
+    std::fill(h.begin(), h.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stats), h.data(), h.size() * 8) != hipSuccess) return GPSCAL_EHIP;
+    return GPSCAL_OK;
+}
+#endif
+
 // The pairs of a batch form `nchains` groups (contiguous halves ...), each with its own dependent chain of
 // step -> solve -> step ...: while one group's solve kernel (one wave per pair, ~9 us of dependent float64
 // arithmetic) runs, the other groups' step kernels keep the chip busy.  Chain c = pairs [chain_pair[c],
@@ -1215,6 +1239,9 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
         std::vector<hipEvent_t> ev((size_t)iters * 2);
         for (auto &e : ev) GPSCAL_HIP(ctx, hipEventCreate(&e));
         for (int it = 0; it < iters; ++it) {
+#ifdef GPSCAL_STATS
+            hipLaunchKernelGGL(stat_set_iter_kernel, dim3(1), dim3(1), 0, ctx->stream, std::min(it, STAT_ITERS - 1));
+#endif
             GPSCAL_HIP(ctx, hipEventRecord(ev[2 * it], ctx->stream));
             launch_step(B, it == iters - 1, -1, ctx->stream);
             GPSCAL_HIP(ctx, hipEventRecord(ev[2 * it + 1], ctx->stream));
