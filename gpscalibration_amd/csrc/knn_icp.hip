@@ -355,9 +355,6 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
 #define GPSCAL_STEP_BLOCK 128  // measured at 64 x 65 536 points, 4 chains: 64 / 128 / 256 threads = 728 / 775 / 746 k iterations/s
 #endif
 constexpr int STEP_BLOCK = GPSCAL_STEP_BLOCK;
-#ifndef GPSCAL_FLAT_ROWS
-#define GPSCAL_FLAT_ROWS 1  // block3_level_flat: the rows after the own one walked as one list per lane
-#endif
 
 template <int QPT, bool WEIGHTED, bool BALL>
 __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
@@ -432,8 +429,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
         STAT_WAVE(2, __ballot(need) != 0ull ? 1 : 0);
         STAT_WAVE(17, __popcll(__ballot(ok && !need && B.pos != BestQ::WARM)));  // settled by tier 2 with a new neighbour
 #endif
-        knn_query<BestQ, BALL, GPSCAL_FLAT_ROWS != 0>(P, sorted, cell_start, need, px, py, pz, B, (diag >> 8) & 0xff,
-                                                     reinterpret_cast<uint2 *>(&tslab[wave][0][0]));
+        knn_query<BestQ, BALL>(P, sorted, cell_start, need, px, py, pz, B, diag >> 8);
         if (!valid) continue;
         ok = ok && B.index() != 0x7fffffff;
         if (ok && B.pos != BestQ::WARM) {
