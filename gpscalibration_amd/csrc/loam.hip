@@ -158,12 +158,22 @@ __device__ __forceinline__ void lo_eigen_sym6(double (&A)[36], double (&Q)[36])
 #pragma unroll
     for (int i = 0; i < 36; ++i) Q[i] = (i % 7 == 0) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
+        // The restatement sweeps until the off-diagonal sum underflows, which rounding residue never lets happen:
+        // it always runs its 60 sweeps, the last ~50 of them rotations by angles below one ulp.  Stopping at
+        // |a_pq| <= 1e-15 sqrt(a_pp a_qq) for every pair (the scaled criterion for positive semi-definite
+        // matrices: small eigenvalues keep their relative accuracy) leaves eigenvalues and vectors within a
+        // few ulps of that result at a tenth of the dependent float64 arithmetic.
         double off = 0;
+        bool conv = true;
 #pragma unroll
         for (int p = 0; p < 6; ++p)
 #pragma unroll
-            for (int q = p + 1; q < 6; ++q) off += A[6 * p + q] * A[6 * p + q];
-        if (off < 1e-300) break;
+            for (int q = p + 1; q < 6; ++q) {
+                const double a2 = A[6 * p + q] * A[6 * p + q];
+                off += a2;
+                conv = conv && a2 <= 1e-30 * fabs(A[7 * p] * A[7 * q]);
+            }
+        if (off < 1e-300 || conv) break;
 #pragma unroll
         for (int p = 0; p < 6; ++p)
 #pragma unroll
@@ -307,7 +317,10 @@ __device__ __forceinline__ void lm_eigen_sym3_top(const double *A_in, double &l1
     for (int i = 0; i < 9; ++i) A[i] = A_in[i];
     for (int sweep = 0; sweep < 50; ++sweep) {
         const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
-        if (off < 1e-300) break;
+        // same stopping rule as lo_eigen_sym6: the restatement's 50 sweeps end in rotations below one ulp
+        const bool conv = A[1] * A[1] <= 1e-30 * fabs(A[0] * A[4]) && A[2] * A[2] <= 1e-30 * fabs(A[0] * A[8]) &&
+                          A[5] * A[5] <= 1e-30 * fabs(A[4] * A[8]);
+        if (off < 1e-300 || conv) break;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll

@@ -25,6 +25,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cmath>
 
 namespace gpscal {
@@ -245,8 +248,11 @@ __global__ void lo_post_kernel(const PostDesc *__restrict__ descs, SegState *__r
 }
 
 // transformMaintenance: laserOdometryHandler (TM:267-314) + SaveTrailWithTimeTotxt (TM:113-157)
+// `lo_sum` is the step's /laser_odom_to_init message (lo_post_kernel wrote it): laserOdometry may already be a
+// sweep ahead when this runs (pipelined chain), SegState::lo_sum is its working copy.
 __global__ void tm_kernel(SegState *__restrict__ st, const int *__restrict__ rows, const double *__restrict__ stamps,
-                          int nseg, float *__restrict__ tm_out, double *__restrict__ track_out)
+                          int nseg, const float *__restrict__ lo_sum, float *__restrict__ tm_out,
+                          double *__restrict__ track_out)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nseg) return;
@@ -254,7 +260,7 @@ __global__ void tm_kernel(SegState *__restrict__ st, const int *__restrict__ row
     if (row < 0) return;
     SegState &S = st[s];
     float sum[6];
-    for (int k = 0; k < 6; ++k) sum[k] = S.lo_sum[k];
+    for (int k = 0; k < 6; ++k) sum[k] = lo_sum[6 * (long long)row + k];
     if (fabs((double)sum[3]) < 0.000001 && fabs((double)sum[4]) < 0.000001 && fabs((double)sum[5]) < 0.000001) {
         S.pre[3] = 0;
         for (int k = 0; k < 6; ++k) S.mBef[k] = S.mAft[k] = 0.f;
@@ -293,7 +299,7 @@ struct PrepDesc {
 __global__ __launch_bounds__(SBLOCK) void lm_prepare_kernel(const PrepDesc *__restrict__ descs, SegState *__restrict__ st,
                                                             PipeDims dims, PipeBufs B, const float4 *__restrict__ clast,
                                                             const float4 *__restrict__ slast, int *__restrict__ sizes,
-                                                            int *__restrict__ status)
+                                                            int *__restrict__ status, const float *__restrict__ lo_sum)
 {
     extern __shared__ unsigned long long dyn_lds[];
     __shared__ BlockShared S;
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(SBLOCK) void lm_prepare_kernel(const PrepDesc *__re
     const int cur = G.cur;
     if (threadIdx.x == 0) {
         float sum[6];
-        for (int k = 0; k < 6; ++k) sum[k] = G.lo_sum[k];
+        for (int k = 0; k < 6; ++k) sum[k] = lo_sum[6 * (long long)s + k];  // the step's odometry message
         if (fabs((double)sum[3]) < 0.000001 && fabs((double)sum[4]) < 0.000001 && fabs((double)sum[5]) < 0.000001)
             G.inited = 0;  // LM:316-319
         for (int k = 0; k < 6; ++k) G.tSum[k] = sum[k];
@@ -734,6 +740,16 @@ using namespace gpscal;
 
 namespace {
 
+// GPSCAL_LOAM_PIPELINE=0: gpscal_loam_run_batched runs the two halves of a step one after the other again
+inline bool loam_pipelined()
+{
+    static const bool on = [] {
+        const char *e = getenv("GPSCAL_LOAM_PIPELINE");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return on;
+}
+
 // The node chain for `nstream` independent streams of sweeps, advanced one sweep per step.  All
 // sweeps are registered (scanRegistration) up front; a step names, per stream, which sweep is
 // published next (or none), and returns what the stream's nodes emitted for it.
@@ -755,25 +771,31 @@ struct LoamPipe {
     DevBuf<float4> b_pool[2][2], b_frommap[2], b_stack2[2], b_stack[2], b_newq[2], b_vin[2], b_vout[2];
     DevBuf<int> b_ts[2][2], b_tc[2][2], b_ns[2], b_nc[2], b_voff[2], b_vcnt[2], b_vocnt[2];
     DevBuf<unsigned long long> b_keys[2], b_vkeys[2];
-    DevBuf<float4> d_clast[2], d_slast[2], d_cmap, d_smap, d_cstack, d_sstack;
+    DevBuf<float4> d_clast[3], d_slast[3], d_cmap, d_smap, d_cstack, d_sstack;  // [NRING]
     DevBuf<PostDesc> d_post;
     DevBuf<PrepDesc> d_prep;
     DevBuf<PackDesc> d_pack;
-    DevBuf<int> d_rows, d_sizes, d_status, d_iters, d_nsel, d_step_it;
-    DevBuf<float> d_tr, d_tr2, d_step_lo, d_step_lm, d_step_tm;
-    DevBuf<double> d_step_track, d_step_stamp;
+    DevBuf<int> d_rows, d_rows_o, d_sizes, d_status, d_iters, d_nsel;
+    DevBuf<float> d_tr, d_tr2, d_mtr, d_mtr2, d_step_lo[3];  // odometry / mapping scratch; [NRING]
+    DevBuf<double> d_step_stamp;
+    // the mapping half's per-step outputs in one block (one fill, one read-back per step): track | lm | tm | iterations
+    DevBuf<char> d_step_out;
+    size_t step_out_bytes = 0;
+    double *d_step_track = nullptr;
+    float *d_step_lm = nullptr, *d_step_tm = nullptr;
+    int *d_step_it = nullptr;
+    std::vector<char> h_step_out;
     std::vector<PostDesc> hpost;
     std::vector<PrepDesc> hprep;
     std::vector<PackDesc> hpack;
     std::vector<SweepDesc> hsw;
     std::vector<MapDesc> hmap;
-    std::vector<int> hrows, hsizes;
+    std::vector<int> hrows, hrows_o, hsizes;
     std::vector<long long> coff, soff, coff_new, soff_new, cmoff, smoff;
     std::vector<double> hstamp;
     // per-stream host state of laserOdometry's bookkeeping
     std::vector<int> local_t;      // sweeps since the last (re)initialisation; 0 = the next sweep seeds
     std::vector<int> frame_count;  // LO:495,1099-1127
-    int lastbuf = 0;
     const double *h_stamps = nullptr;
 
     int init(gpscal_ctx *c, int nstream_, const float *xyz, const int *sweep_off_, int nsw_, const double *stamps,
@@ -862,9 +884,11 @@ struct LoamPipe {
             B.keys[t] = b_keys[t].p;
             B.vkeys[t] = b_vkeys[t].p;
         }
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NRING; ++k) {
             GPSCAL_HIP(ctx, d_clast[k].alloc((size_t)nseg * max_ls));
             GPSCAL_HIP(ctx, d_slast[k].alloc((size_t)nseg * max_lf));
+            GPSCAL_HIP(ctx, d_step_lo[k].alloc((size_t)nseg * 6));
+            GPSCAL_HIP(ctx, hipMemsetAsync(d_step_lo[k].p, 0, sizeof(float) * 6 * nseg, q));
         }
         GPSCAL_HIP(ctx, d_cmap.alloc((size_t)nseg * dims.cap[0]));
         GPSCAL_HIP(ctx, d_smap.alloc((size_t)nseg * dims.cap[1]));
@@ -874,18 +898,23 @@ struct LoamPipe {
         GPSCAL_HIP(ctx, d_prep.alloc(nseg));
         GPSCAL_HIP(ctx, d_pack.alloc(nseg));
         GPSCAL_HIP(ctx, d_rows.alloc(nseg));
+        GPSCAL_HIP(ctx, d_rows_o.alloc(nseg));
         GPSCAL_HIP(ctx, d_sizes.alloc((size_t)nseg * 4));
         GPSCAL_HIP(ctx, d_status.alloc(1));
         GPSCAL_HIP(ctx, d_iters.alloc(nseg));
         GPSCAL_HIP(ctx, d_nsel.alloc(nseg));
         GPSCAL_HIP(ctx, d_tr.alloc((size_t)nseg * 6));
         GPSCAL_HIP(ctx, d_tr2.alloc((size_t)nseg * 6));
-        GPSCAL_HIP(ctx, d_step_lo.alloc((size_t)nseg * 6));
-        GPSCAL_HIP(ctx, d_step_lm.alloc((size_t)nseg * 6));
-        GPSCAL_HIP(ctx, d_step_tm.alloc((size_t)nseg * 6));
-        GPSCAL_HIP(ctx, d_step_track.alloc((size_t)nseg * 4));
+        GPSCAL_HIP(ctx, d_mtr.alloc((size_t)nseg * 6));
+        GPSCAL_HIP(ctx, d_mtr2.alloc((size_t)nseg * 6));
         GPSCAL_HIP(ctx, d_step_stamp.alloc((size_t)nseg));
-        GPSCAL_HIP(ctx, d_step_it.alloc((size_t)nseg));
+        step_out_bytes = (size_t)nseg * (4 * sizeof(double) + 12 * sizeof(float) + sizeof(int));
+        GPSCAL_HIP(ctx, d_step_out.alloc(step_out_bytes));
+        d_step_track = reinterpret_cast<double *>(d_step_out.p);
+        d_step_lm = reinterpret_cast<float *>(d_step_track + (size_t)nseg * 4);
+        d_step_tm = d_step_lm + (size_t)nseg * 6;
+        d_step_it = reinterpret_cast<int *>(d_step_tm + (size_t)nseg * 6);
+        h_step_out.resize(step_out_bytes);
         GPSCAL_HIP(ctx, hipMemsetAsync(d_status.p, 0, sizeof(int), q));
         hpost.resize(nseg);
         hprep.resize(nseg);
@@ -893,6 +922,7 @@ struct LoamPipe {
         hsw.resize(nseg);
         hmap.resize(nseg);
         hrows.resize(nseg);
+        hrows_o.resize(nseg);
         hsizes.resize((size_t)nseg * 4);
         hstamp.resize(nseg);
         coff.assign(nseg + 1, 0);
@@ -912,30 +942,49 @@ struct LoamPipe {
     // /control_command with systemInited = false (ID:283-286, 342-346; LO:411-415)
     void control_reset(int s) { local_t[s] = 0; }
 
-    // One sweep per stream (sweep_idx[s] < 0: the stream idles).  Host outputs, nstream rows each:
-    // published[s] (odometry emitted), mapped[s] (laserMapping ran), lo / lm / tm poses, track, iters.
-    double t_sec[6] = {0, 0, 0, 0, 0, 0};  // GPSCAL_LOAM_TIMING: host wall seconds per section of step()
-    int step(const int *sweep_idx, int *published, int *mapped, float *lo, float *lm, float *tm, double *track,
-             int *iters)
+    // What the odometry half of a step hands to the mapping half.  The new "last" clouds and the step's
+    // transformSum live in ring entry `buf` of d_clast / d_slast / d_step_lo.
+    struct StepSlot {
+        std::vector<int> published, do_map, rows_tm;
+        std::vector<double> stamp;
+        std::vector<long long> coff, soff;
+        bool any_tm = false, any_map = false;
+        int buf = 0;
+    };
+    static constexpr int NRING = 3;  // laserOdometry may run two sweeps ahead of laserMapping (sizes of d_clast ...)
+    StepSlot slots[NRING];
+    long long step_no = 0;  // steps started by step_odo
+
+    double t_sec[6] = {0, 0, 0, 0, 0, 0};  // GPSCAL_LOAM_TIMING: host wall seconds per section of a step
+    typedef std::chrono::steady_clock clk;
+    void t_add(int k, clk::time_point a) { t_sec[k] += std::chrono::duration<double>(clk::now() - a).count(); }
+
+    // Odometry half of a step, on c->stream (the chain's own context, or a clone of it with another stream
+    // when the halves run concurrently): laserOdometry for the named sweeps, then the new "last" clouds
+    // (LO:1087-1114) and the step's transformSum into ring entry L.buf.  Synchronises c->stream.
+    int step_odo(gpscal_ctx *c, const int *sweep_idx, StepSlot &L)
     {
-        typedef std::chrono::steady_clock clk;
-        auto t_now = [] { return clk::now(); };
-        auto t_add = [&](int k, clk::time_point a) { t_sec[k] += std::chrono::duration<double>(clk::now() - a).count(); };
-        auto t0 = t_now();
-        hipStream_t q = ctx->stream;
+        auto t0 = clk::now();
+        hipStream_t q = c->stream;
         const int nseg = nstream;
         SegState *S = d_state.p;
-        const int newbuf = lastbuf ^ 1;
-        const size_t lds_keys = sizeof(unsigned long long) * LDS_KEYS;
+        const int newbuf = (int)(step_no % NRING), lastbuf = (int)((step_no + NRING - 1) % NRING);
+        ++step_no;
+        L.buf = newbuf;
+        L.published.assign(nseg, 0);
+        L.do_map.assign(nseg, 0);
+        L.rows_tm.assign(nseg, -1);
+        L.stamp.assign(nseg, 0.0);
+        L.any_tm = L.any_map = false;
         coff_new[0] = soff_new[0] = 0;
-        bool any_match = false, any_tm = false, any_map = false;
-        std::vector<int> do_map(nseg, 0);
+        bool any_match = false;
         for (int s = 0; s < nseg; ++s) {
             const int g = sweep_idx[s];
             const bool act = g >= 0;
             const bool seed = act && local_t[s] == 0;
-            hrows[s] = act && !seed ? s : -1;  // odometry (and everything after it) is published
-            hstamp[s] = act ? h_stamps[g] : 0.0;
+            hrows_o[s] = act && !seed ? s : -1;  // odometry (and everything after it) is published
+            L.rows_tm[s] = hrows_o[s];
+            L.stamp[s] = act ? h_stamps[g] : 0.0;
             PostDesc &P = hpost[s];
             P.row = act ? s : -1;
             P.nc = act ? cnt[5 * g + 2] : 0;
@@ -971,69 +1020,86 @@ struct LoamPipe {
                 hring_s[16 * (size_t)s + r] = last_sweep[s] >= 0 ? ring_cnt[32 * (size_t)last_sweep[s] + 16 + r] : 0;
             }
             any_match = any_match || (act && !seed);
-            published[s] = act && !seed;
-            any_tm = any_tm || published[s];
-            if (published[s]) {
+            L.published[s] = act && !seed;
+            L.any_tm = L.any_tm || L.published[s];
+            if (L.published[s]) {
                 if (++frame_count[s] >= 2) {  // skipFrameNum + 1, LO:1099-1127
                     frame_count[s] = 0;
-                    do_map[s] = 1;
-                    any_map = true;
+                    L.do_map[s] = 1;
+                    L.any_map = true;
                 }
             }
-            mapped[s] = do_map[s];
         }
-        GPSCAL_HIP(ctx, hipMemcpyAsync(d_rows.p, hrows.data(), sizeof(int) * nseg, hipMemcpyHostToDevice, q));
-        GPSCAL_HIP(ctx, hipMemcpyAsync(d_post.p, hpost.data(), sizeof(PostDesc) * nseg, hipMemcpyHostToDevice, q));
-        GPSCAL_HIP(ctx, hipMemcpyAsync(d_step_stamp.p, hstamp.data(), sizeof(double) * nseg, hipMemcpyHostToDevice, q));
-        GPSCAL_HIP(ctx, hipMemsetAsync(d_step_lm.p, 0xff, sizeof(float) * 6 * nseg, q));
-        GPSCAL_HIP(ctx, hipMemsetAsync(d_step_tm.p, 0xff, sizeof(float) * 6 * nseg, q));
-        GPSCAL_HIP(ctx, hipMemsetAsync(d_step_track.p, 0xff, sizeof(double) * 4 * nseg, q));
-        GPSCAL_HIP(ctx, hipMemsetAsync(d_step_it.p, 0xff, sizeof(int) * nseg, q));
+        GPSCAL_HIP(c, hipMemcpyAsync(d_rows_o.p, hrows_o.data(), sizeof(int) * nseg, hipMemcpyHostToDevice, q));
+        GPSCAL_HIP(c, hipMemcpyAsync(d_post.p, hpost.data(), sizeof(PostDesc) * nseg, hipMemcpyHostToDevice, q));
         t_add(0, t0);
-        t0 = t_now();
+        t0 = clk::now();
         if (any_match) {
             // transform / transformSum live in SegState; the kernels take flat [nstream][6] arrays.  A
             // stream that idles or seeds has empty clouds here: its state passes through unchanged
             // (zero transform accumulates to itself only for a zero sum, so those rows are restored).
-            hipLaunchKernelGGL(lo_state_kernel, dim3(div_up(nseg * 6, 64)), dim3(64), 0, q, S, nseg, d_tr.p, d_tr2.p, d_rows.p, 0);
-            int rc = loam_odometry_device(ctx, nseg, hsw.data(), d_sharp.p, d_flat.p, d_clast[lastbuf].p, d_slast[lastbuf].p,
+            hipLaunchKernelGGL(lo_state_kernel, dim3(div_up(nseg * 6, 64)), dim3(64), 0, q, S, nseg, d_tr.p, d_tr2.p, d_rows_o.p, 0);
+            int rc = loam_odometry_device(c, nseg, hsw.data(), d_sharp.p, d_flat.p, d_clast[lastbuf].p, d_slast[lastbuf].p,
                                           coff.data(), soff.data(), d_tr.p, d_tr.p, nullptr, nullptr, d_tr2.p, d_tr2.p,
                                           hring_c.data(), hring_s.data());
             if (rc) return rc;
-            hipLaunchKernelGGL(lo_state_kernel, dim3(div_up(nseg * 6, 64)), dim3(64), 0, q, S, nseg, d_tr.p, d_tr2.p, d_rows.p, 1);
+            hipLaunchKernelGGL(lo_state_kernel, dim3(div_up(nseg * 6, 64)), dim3(64), 0, q, S, nseg, d_tr.p, d_tr2.p, d_rows_o.p, 1);
         }
-        t_add(1, t0);
-        t0 = t_now();
         {
             const int gx = std::max(1, std::min(div_up(std::max(max_ls + max_lf, 1), 256), 64));
             hipLaunchKernelGGL(lo_post_kernel, dim3(gx, nseg), dim3(256), 0, q, d_post.p, S, d_lsharp.p, d_lflat.p,
                                d_clast[lastbuf].p, d_slast[lastbuf].p, d_clast[newbuf].p, d_slast[newbuf].p,
-                               d_step_lo.p);
-            GPSCAL_HIP(ctx, hipGetLastError());
+                               d_step_lo[newbuf].p);
+            GPSCAL_HIP(c, hipGetLastError());
         }
-        lastbuf = newbuf;
         coff = coff_new;
         soff = soff_new;
-        if (any_tm) {
+        L.coff = coff;
+        L.soff = soff;
+        for (int s = 0; s < nseg; ++s)
+            if (sweep_idx[s] >= 0) {
+                ++local_t[s];
+                last_sweep[s] = sweep_idx[s];
+            }
+        GPSCAL_HIP(c, hipStreamSynchronize(q));  // the hand-over to the mapping half is a host-side one
+        t_add(1, t0);
+        return GPSCAL_OK;
+    }
+
+    // Mapping half of a step, on ctx->stream: transformMaintenance, laserMapping (every second published
+    // sweep) and the step's host outputs (nstream rows each): lo / lm / tm poses, track, iterations.
+    int step_map(const StepSlot &L, float *lo, float *lm, float *tm, double *track, int *iters)
+    {
+        auto t0 = clk::now();
+        hipStream_t q = ctx->stream;
+        const int nseg = nstream;
+        SegState *S = d_state.p;
+        const int buf = L.buf;
+        const size_t lds_keys = sizeof(unsigned long long) * LDS_KEYS;
+        const std::vector<long long> &coff = L.coff, &soff = L.soff;
+        GPSCAL_HIP(ctx, hipMemsetAsync(d_step_out.p, 0xff, step_out_bytes, q));  // lm | tm | track | iterations
+        if (L.any_tm) {
+            GPSCAL_HIP(ctx, hipMemcpyAsync(d_rows.p, L.rows_tm.data(), sizeof(int) * nseg, hipMemcpyHostToDevice, q));
+            GPSCAL_HIP(ctx, hipMemcpyAsync(d_step_stamp.p, L.stamp.data(), sizeof(double) * nseg, hipMemcpyHostToDevice, q));
             hipLaunchKernelGGL(tm_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, d_rows.p, d_step_stamp.p, nseg,
-                               d_step_tm.p, d_step_track.p);
+                               d_step_lo[buf].p, d_step_tm, d_step_track);
             GPSCAL_HIP(ctx, hipGetLastError());
         }
-        if (any_map) {
+        if (L.any_map) {
             for (int s = 0; s < nseg; ++s) {
                 PrepDesc &P = hprep[s];
                 P.clast_off = coff[s];
                 P.slast_off = soff[s];
                 P.nc = (int)(coff[s + 1] - coff[s]);
                 P.ns = (int)(soff[s + 1] - soff[s]);
-                P.active = do_map[s];
+                P.active = L.do_map[s];
                 P.pad = 0;
-                hrows[s] = do_map[s] ? s : -1;
+                hrows[s] = L.do_map[s] ? s : -1;
             }
             GPSCAL_HIP(ctx, hipMemcpyAsync(d_rows.p, hrows.data(), sizeof(int) * nseg, hipMemcpyHostToDevice, q));
             GPSCAL_HIP(ctx, hipMemcpyAsync(d_prep.p, hprep.data(), sizeof(PrepDesc) * nseg, hipMemcpyHostToDevice, q));
             hipLaunchKernelGGL(lm_prepare_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, d_prep.p, S, dims, B,
-                               d_clast[lastbuf].p, d_slast[lastbuf].p, d_sizes.p, d_status.p);
+                               d_clast[buf].p, d_slast[buf].p, d_sizes.p, d_status.p, d_step_lo[buf].p);
             GPSCAL_HIP(ctx, hipGetLastError());
             GPSCAL_HIP(ctx, hipMemcpyAsync(hsizes.data(), d_sizes.p, sizeof(int) * hsizes.size(), hipMemcpyDeviceToHost, q));
             GPSCAL_HIP(ctx, hipStreamSynchronize(q));
@@ -1055,39 +1121,55 @@ struct LoamPipe {
                 nmax = std::max(nmax, std::max(std::max(mc, ms), std::max(nc, ns)));
             }
             t_add(2, t0);
-            t0 = t_now();
+            t0 = clk::now();
             GPSCAL_HIP(ctx, hipMemcpyAsync(d_pack.p, hpack.data(), sizeof(PackDesc) * nseg, hipMemcpyHostToDevice, q));
             hipLaunchKernelGGL(lm_pack_kernel, dim3(std::max(1, std::min(div_up(nmax, 256), 128)), nseg), dim3(256), 0, q,
                                d_pack.p, dims, B, d_cmap.p, d_smap.p, d_cstack.p, d_sstack.p);
             GPSCAL_HIP(ctx, hipGetLastError());
-            GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_tr.p, 24, &S[0].tTobe[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
+            GPSCAL_HIP(ctx, hipMemcpy2DAsync(d_mtr.p, 24, &S[0].tTobe[0], sizeof(SegState), 24, nseg, hipMemcpyDeviceToDevice, q));
             int rc = loam_mapping_device(ctx, nseg, hmap.data(), d_cstack.p, d_sstack.p, d_cmap.p, d_smap.p, cmoff.data(),
-                                         smoff.data(), d_tr.p, d_tr2.p, d_iters.p, d_nsel.p);
+                                         smoff.data(), d_mtr.p, d_mtr2.p, d_iters.p, d_nsel.p);
             if (rc) return rc;
             t_add(3, t0);
-            t0 = t_now();
-            hipLaunchKernelGGL(lm_insert_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, S, dims, B, d_sizes.p, d_tr2.p,
-                               d_iters.p, d_rows.p, d_step_lm.p, d_step_it.p, d_status.p);
+            t0 = clk::now();
+            hipLaunchKernelGGL(lm_insert_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, S, dims, B, d_sizes.p, d_mtr2.p,
+                               d_iters.p, d_rows.p, d_step_lm, d_step_it, d_status.p);
             hipLaunchKernelGGL(lm_filter_kernel, dim3(MAXVALID, nseg * 2), dim3(SBLOCK), lds_keys, q, S, dims, B, d_status.p);
             hipLaunchKernelGGL(lm_rebuild_kernel, dim3(nseg * 2), dim3(SBLOCK), 0, q, S, dims, B, d_status.p);
             hipLaunchKernelGGL(lm_flip_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, nseg);
             GPSCAL_HIP(ctx, hipGetLastError());
         }
         t_add(4, t0);
-        t0 = t_now();
-        if (lo) GPSCAL_HIP(ctx, hipMemcpyAsync(lo, d_step_lo.p, sizeof(float) * 6 * nseg, hipMemcpyDeviceToHost, q));
-        if (lm) GPSCAL_HIP(ctx, hipMemcpyAsync(lm, d_step_lm.p, sizeof(float) * 6 * nseg, hipMemcpyDeviceToHost, q));
-        if (tm) GPSCAL_HIP(ctx, hipMemcpyAsync(tm, d_step_tm.p, sizeof(float) * 6 * nseg, hipMemcpyDeviceToHost, q));
-        if (iters) GPSCAL_HIP(ctx, hipMemcpyAsync(iters, d_step_it.p, sizeof(int) * nseg, hipMemcpyDeviceToHost, q));
-        GPSCAL_HIP(ctx, hipMemcpyAsync(track, d_step_track.p, sizeof(double) * 4 * nseg, hipMemcpyDeviceToHost, q));
+        t0 = clk::now();
+        // one read-back for the step: lm | tm | track | iterations, then laserOdometry's transformSum
+        GPSCAL_HIP(ctx, hipMemcpyAsync(h_step_out.data(), d_step_out.p, step_out_bytes, hipMemcpyDeviceToHost, q));
+        if (lo) GPSCAL_HIP(ctx, hipMemcpyAsync(lo, d_step_lo[buf].p, sizeof(float) * 6 * nseg, hipMemcpyDeviceToHost, q));
         GPSCAL_HIP(ctx, hipStreamSynchronize(q));
+        {
+            const char *h = h_step_out.data();
+            if (lm) memcpy(lm, h + ((const char *)d_step_lm - (const char *)d_step_out.p), sizeof(float) * 6 * nseg);
+            if (tm) memcpy(tm, h + ((const char *)d_step_tm - (const char *)d_step_out.p), sizeof(float) * 6 * nseg);
+            if (iters) memcpy(iters, h + ((const char *)d_step_it - (const char *)d_step_out.p), sizeof(int) * nseg);
+            memcpy(track, h + ((const char *)d_step_track - (const char *)d_step_out.p), sizeof(double) * 4 * nseg);
+        }
         t_add(5, t0);
-        for (int s = 0; s < nseg; ++s)
-            if (sweep_idx[s] >= 0) {
-                ++local_t[s];
-                last_sweep[s] = sweep_idx[s];
-            }
         return GPSCAL_OK;
+    }
+
+    // One sweep per stream (sweep_idx[s] < 0: the stream idles), both halves one after the other on the
+    // chain's stream.  Host outputs, nstream rows each: published[s] (odometry emitted), mapped[s]
+    // (laserMapping ran), lo / lm / tm poses, track, iters.
+    int step(const int *sweep_idx, int *published, int *mapped, float *lo, float *lm, float *tm, double *track,
+             int *iters)
+    {
+        StepSlot &L = slots[step_no % NRING];
+        int rc = step_odo(ctx, sweep_idx, L);
+        if (rc) return rc;
+        for (int s = 0; s < nstream; ++s) {
+            published[s] = L.published[s];
+            mapped[s] = L.do_map[s];
+        }
+        return step_map(L, lo, lm, tm, track, iters);
     }
 
     int finish()
@@ -1147,13 +1229,13 @@ extern "C" int gpscal_loam_run_batched(gpscal_ctx *ctx, int nseg, const float *x
         std::vector<int> idx(ng), pub(ng), mapd(ng), its(ng);
         std::vector<float> lo((size_t)ng * 6), lm((size_t)ng * 6), tm((size_t)ng * 6);
         std::vector<double> tr((size_t)ng * 4);
-        for (int t = 0; t < gmax; ++t) {
+        auto sweeps_of_step = [&](int t, int *out) {
             for (int s = 0; s < ng; ++s) {
                 const int a0 = seg_sweep_off[s0 + s], a1 = seg_sweep_off[s0 + s + 1];
-                idx[s] = t < a1 - a0 ? a0 + t - w0 : -1;
+                out[s] = t < a1 - a0 ? a0 + t - w0 : -1;
             }
-            rc = P.step(idx.data(), pub.data(), mapd.data(), lo.data(), lm.data(), tm.data(), tr.data(), its.data());
-            if (rc) return rc;
+        };
+        auto scatter = [&]() {
             for (int s = 0; s < ng; ++s) {
                 if (idx[s] < 0) continue;
                 const size_t g = (size_t)idx[s] + w0;
@@ -1165,6 +1247,84 @@ extern "C" int gpscal_loam_run_batched(gpscal_ctx *ctx, int nseg, const float *x
                 for (int k = 0; k < 4; ++k) track_xyzt[4 * g + k] = pub[s] ? tr[4 * s + k] : dnan;
                 if (lm_iters_out) lm_iters_out[g] = mapd[s] ? its[s] : -1;
             }
+        };
+        if (!loam_pipelined() || gmax < 2) {
+            for (int t = 0; t < gmax; ++t) {
+                sweeps_of_step(t, idx.data());
+                rc = P.step(idx.data(), pub.data(), mapd.data(), lo.data(), lm.data(), tm.data(), tr.data(), its.data());
+                if (rc) return rc;
+                scatter();
+            }
+        } else {
+            // The nodes run concurrently, as the reference's ROS nodes do: laserOdometry (this thread's twin, on
+            // its own stream) works up to two sweeps ahead of transformMaintenance + laserMapping (this thread,
+            // on the context's stream).  Nothing flows back from mapping to odometry (LO subscribes to
+            // scanRegistration's topics only), so the results are those of the lock-step order.
+            gpscal_ctx octx = *ctx;  // same device, another stream; errors are copied back
+            hipStream_t os = nullptr;
+            GPSCAL_HIP(ctx, hipStreamCreateWithFlags(&os, hipStreamNonBlocking));
+            octx.stream = os;
+            std::mutex mu;
+            std::condition_variable cv;
+            int produced = 0, consumed = 0, rc_o = 0;
+            bool stop = false;
+            std::thread odo([&] {
+                (void)hipSetDevice(ctx->device);
+                std::vector<int> oidx(ng);
+                for (int t = 0; t < gmax; ++t) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || consumed >= t - (LoamPipe::NRING - 1); });
+                        if (stop) return;
+                    }
+                    sweeps_of_step(t, oidx.data());
+                    const int r = P.step_odo(&octx, oidx.data(), P.slots[t % LoamPipe::NRING]);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (r) {
+                            rc_o = r;
+                            stop = true;
+                        } else
+                            produced = t + 1;
+                    }
+                    cv.notify_all();
+                    if (r) return;
+                }
+            });
+            int rc_m = 0;
+            for (int t = 0; t < gmax; ++t) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || produced > t; });
+                    if (produced <= t) break;  // the odometry half failed
+                }
+                const LoamPipe::StepSlot &L = P.slots[t % LoamPipe::NRING];
+                rc_m = P.step_map(L, lo.data(), lm.data(), tm.data(), tr.data(), its.data());
+                if (!rc_m) {
+                    sweeps_of_step(t, idx.data());
+                    for (int s = 0; s < ng; ++s) {
+                        pub[s] = L.published[s];
+                        mapd[s] = L.do_map[s];
+                    }
+                    scatter();
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    consumed = t + 1;
+                    if (rc_m) stop = true;
+                }
+                cv.notify_all();
+                if (rc_m) break;
+            }
+            odo.join();
+            (void)hipStreamSynchronize(os);
+            cache_trim(os);
+            (void)hipStreamDestroy(os);
+            if (rc_o) {
+                ctx->last_error = octx.last_error;
+                return rc_o;
+            }
+            if (rc_m) return rc_m;
         }
         rc = P.finish();
         if (rc) return rc;
