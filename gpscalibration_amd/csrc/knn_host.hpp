@@ -28,6 +28,14 @@ struct GridSet {
 // tiled single-level grouping used for source clouds.
 int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long long *off, int npairs, float cell,
                 int max_levels, GridSet &gs);
+// Several clouds-of-clouds in one call, with one host wait for all of them (the bounding boxes).
+struct GridSource {
+    const void *xyz;
+    const long long *off;
+    int npairs;
+    GridSet *gs;
+};
+int build_grids_multi(gpscal_ctx *ctx, int nsrc, const GridSource *src, int stride, float cell, int max_levels);
 // Neighbour lists + certified radii (ICP only).
 int ensure_safe_radius(gpscal_ctx *ctx, GridSet &gs);
 

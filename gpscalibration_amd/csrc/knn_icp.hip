@@ -735,113 +735,151 @@ static void plan_levels(const float mn[3], const float mx[3], int m, float cell,
     }
 }
 
-int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long long *off, int npairs,
-                       float cell, int max_levels, GridSet &gs)
+// Grid sets for several clouds-of-clouds at once (the LOAM nodes index two to four of them per sweep): the
+// bounding boxes of all of them come back in ONE read-back, which is the only point where the host waits --
+// the grid dimensions are planned on the host.  Pooled sets (per-call sets of the LOAM chain) are not
+// synchronised at the end either: their temporaries go back to the stream's block cache in stream order.
+int build_grids_multi(gpscal_ctx *ctx, int nsrc, const GridSource *src, int stride, float cell, int max_levels)
 {
-    gs.ctx = ctx;
-    gs.npairs = npairs;
-    gs.off.assign(off, off + npairs + 1);
-    const long long total = off[npairs] - off[0];
-    if (total < 0) return fail(ctx, GPSCAL_EINVAL, "negative point count");
     if (stride < 12) return fail(ctx, GPSCAL_EINVAL, "stride_bytes must be >= 12");
-    InArg<char> raw;
-    GPSCAL_HIP(ctx, raw.bind(ctx, static_cast<const char *>(xyz) + (size_t)off[0] * stride, (size_t)total * stride));
-    GPSCAL_HIP(ctx, gs.pooled ? gs.pts4.alloc_async((size_t)total, ctx->stream) : gs.pts4.alloc((size_t)total));
-    DevBuf<long long> d_off;
-    GPSCAL_HIP(ctx, d_off.alloc_async(npairs + 1, ctx->stream));
-    std::vector<long long> rel(npairs + 1);
-    for (int b = 0; b <= npairs; ++b) rel[b] = off[b] - off[0];
-    GPSCAL_HIP(ctx, hipMemcpyAsync(d_off.p, rel.data(), sizeof(long long) * (npairs + 1), hipMemcpyHostToDevice,
-                                   ctx->stream));
-    int mmax = 0;
-    for (int b = 0; b < npairs; ++b) {
-        long long m = rel[b + 1] - rel[b];
-        if (m < 0 || m > 0x7fffffff) return fail(ctx, GPSCAL_EINVAL, "bad offsets");
-        mmax = std::max(mmax, (int)m);
+    struct Part {
+        std::vector<long long> rel;
+        DevBuf<long long> d_off;
+        InArg<char> raw;
+        long long total = 0, bbox_at = 0;
+        int mmax = 0;
+    };
+    std::vector<Part> parts(nsrc);
+    long long nbox = 0;
+    for (int k = 0; k < nsrc; ++k) {
+        parts[k].bbox_at = nbox;
+        nbox += src[k].npairs;
     }
-    if (total > 0)
-        hipLaunchKernelGGL(pack_points_kernel, dim3(div_up(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, raw.dev,
-                           stride, d_off.p, npairs, total, gs.pts4.p);
-    // bounding boxes
     DevBuf<int> d_bbox;
-    GPSCAL_HIP(ctx, d_bbox.alloc_async((size_t)npairs * 6, ctx->stream));
-    std::vector<int> hb((size_t)npairs * 6);
-    for (int b = 0; b < npairs; ++b)
+    GPSCAL_HIP(ctx, d_bbox.alloc_async((size_t)std::max<long long>(nbox, 1) * 6, ctx->stream));
+    std::vector<int> hb((size_t)std::max<long long>(nbox, 1) * 6);
+    for (long long b = 0; b < nbox; ++b)
         for (int a = 0; a < 3; ++a) {
             hb[b * 6 + a] = 0x7fffffff;
             hb[b * 6 + 3 + a] = (int)0x80000000;
         }
     GPSCAL_HIP(ctx, hipMemcpyAsync(d_bbox.p, hb.data(), sizeof(int) * hb.size(), hipMemcpyHostToDevice, ctx->stream));
-    int gx = std::max(1, std::min(div_up(mmax, BLOCK * 4), 256));
-    if (npairs > 0 && mmax > 0)
-        hipLaunchKernelGGL(bbox_kernel, dim3(gx, npairs), dim3(BLOCK), 0, ctx->stream, gs.pts4.p, d_off.p, d_bbox.p);
+    for (int k = 0; k < nsrc; ++k) {
+        GridSet &gs = *src[k].gs;
+        Part &W = parts[k];
+        const long long *off = src[k].off;
+        const int npairs = src[k].npairs;
+        gs.ctx = ctx;
+        gs.npairs = npairs;
+        gs.off.assign(off, off + npairs + 1);
+        W.total = off[npairs] - off[0];
+        if (W.total < 0) return fail(ctx, GPSCAL_EINVAL, "negative point count");
+        GPSCAL_HIP(ctx, W.raw.bind(ctx, static_cast<const char *>(src[k].xyz) + (size_t)off[0] * stride,
+                                   (size_t)W.total * stride));
+        GPSCAL_HIP(ctx, gs.pooled ? gs.pts4.alloc_async((size_t)W.total, ctx->stream) : gs.pts4.alloc((size_t)W.total));
+        GPSCAL_HIP(ctx, W.d_off.alloc_async(npairs + 1, ctx->stream));
+        W.rel.resize(npairs + 1);
+        for (int b = 0; b <= npairs; ++b) W.rel[b] = off[b] - off[0];
+        GPSCAL_HIP(ctx, hipMemcpyAsync(W.d_off.p, W.rel.data(), sizeof(long long) * (npairs + 1), hipMemcpyHostToDevice,
+                                       ctx->stream));
+        for (int b = 0; b < npairs; ++b) {
+            long long m = W.rel[b + 1] - W.rel[b];
+            if (m < 0 || m > 0x7fffffff) return fail(ctx, GPSCAL_EINVAL, "bad offsets");
+            W.mmax = std::max(W.mmax, (int)m);
+        }
+        if (W.total > 0)
+            hipLaunchKernelGGL(pack_points_kernel, dim3(div_up(W.total, BLOCK)), dim3(BLOCK), 0, ctx->stream, W.raw.dev,
+                               stride, W.d_off.p, npairs, W.total, gs.pts4.p);
+        // bounding boxes
+        const int gx = std::max(1, std::min(div_up(W.mmax, BLOCK * 4), 256));
+        if (npairs > 0 && W.mmax > 0)
+            hipLaunchKernelGGL(bbox_kernel, dim3(gx, npairs), dim3(BLOCK), 0, ctx->stream, gs.pts4.p, W.d_off.p,
+                               d_bbox.p + W.bbox_at * 6);
+    }
     GPSCAL_HIP(ctx, hipMemcpyAsync(hb.data(), d_bbox.p, sizeof(int) * hb.size(), hipMemcpyDeviceToHost, ctx->stream));
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
-    gs.hpairs.assign(npairs, PairDesc{});
-    long long cells = 0, sorted_total = 0;
-    for (int b = 0; b < npairs; ++b) {
-        PairDesc &P = gs.hpairs[b];
-        P.tgt_off = rel[b];
-        P.m = (int)(rel[b + 1] - rel[b]);
-        float mn[3], mx[3];
-        for (int a = 0; a < 3; ++a) {
-            mn[a] = ord2f(hb[b * 6 + a]);
-            mx[a] = ord2f(hb[b * 6 + 3 + a]);
-            if (!(mn[a] <= mx[a])) mn[a] = mx[a] = 0.f;  // empty / all-NaN cloud
-        }
-        plan_levels(mn, mx, P.m, cell, max_levels, P);
-        // levels whose cells (counted from the top) fit the LDS histogram are aggregated there
-        {
-            long long acc = 0;
-            P.coarse_from = P.nlevels;
-            for (int l = P.nlevels - 1; l >= 0; --l) {
+    bool all_pooled = true;
+    for (int k = 0; k < nsrc; ++k) {
+        GridSet &gs = *src[k].gs;
+        Part &W = parts[k];
+        const int npairs = src[k].npairs;
+        const std::vector<long long> &rel = W.rel;
+        const int *hbk = hb.data() + W.bbox_at * 6;
+        all_pooled = all_pooled && gs.pooled;
+        gs.hpairs.assign(npairs, PairDesc{});
+        long long cells = 0, sorted_total = 0;
+        for (int b = 0; b < npairs; ++b) {
+            PairDesc &P = gs.hpairs[b];
+            P.tgt_off = rel[b];
+            P.m = (int)(rel[b + 1] - rel[b]);
+            float mn[3], mx[3];
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = ord2f(hbk[b * 6 + a]);
+                mx[a] = ord2f(hbk[b * 6 + 3 + a]);
+                if (!(mn[a] <= mx[a])) mn[a] = mx[a] = 0.f;  // empty / all-NaN cloud
+            }
+            plan_levels(mn, mx, P.m, cell, max_levels, P);
+            // levels whose cells (counted from the top) fit the LDS histogram are aggregated there
+            {
+                long long acc = 0;
+                P.coarse_from = P.nlevels;
+                for (int l = P.nlevels - 1; l >= 0; --l) {
+                    const GridDesc &G = P.lv[l];
+                    acc += grid_cells(G);
+                    if (acc > CO_MAX) break;
+                    P.coarse_from = l;
+                }
+            }
+            for (int l = 0; l < P.nlevels; ++l) {
+                P.lv[l].cell_base = cells;
                 const GridDesc &G = P.lv[l];
-                acc += grid_cells(G);
-                if (acc > CO_MAX) break;
-                P.coarse_from = l;
+                cells += grid_cells(G);
+                sorted_total += P.m;
             }
         }
-        for (int l = 0; l < P.nlevels; ++l) {
-            P.lv[l].cell_base = cells;
-            const GridDesc &G = P.lv[l];
-            cells += grid_cells(G);
-            sorted_total += P.m;
+        if (sorted_total >= (1ll << 32) - 1) return fail(ctx, GPSCAL_ERANGE, "batch too large for 32-bit cell offsets");
+        gs.total_cells = cells;
+        gs.total_sorted = sorted_total;
+        GPSCAL_HIP(ctx, gs.pooled ? gs.pairs.alloc_async(npairs, ctx->stream) : gs.pairs.alloc(npairs));
+        GPSCAL_HIP(ctx, hipMemcpyAsync(gs.pairs.p, gs.hpairs.data(), sizeof(PairDesc) * npairs, hipMemcpyHostToDevice,
+                                       ctx->stream));
+        DevBuf<unsigned> counts;
+        GPSCAL_HIP(ctx, counts.alloc_async((size_t)cells + 1, ctx->stream));
+        GPSCAL_HIP(ctx, gs.pooled ? gs.cell_start_buf.alloc_async((size_t)cells + 1 + 8, ctx->stream)
+                                  : gs.cell_start_buf.alloc((size_t)cells + 1 + 8));
+        GPSCAL_HIP(ctx, hipMemsetAsync(gs.cell_start_buf.p, 0, sizeof(unsigned) * ((size_t)cells + 9), ctx->stream));
+        gs.cell_start = gs.cell_start_buf.p + 4;
+        GPSCAL_HIP(ctx, gs.pooled ? gs.sorted.alloc_async((size_t)sorted_total, ctx->stream) : gs.sorted.alloc((size_t)sorted_total));
+        GPSCAL_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
+        if (npairs > 0 && W.mmax > 0) {
+            int maxlev = 1;
+            for (auto &P : gs.hpairs) maxlev = std::max(maxlev, P.nlevels);
+            DevBuf<unsigned> ranks;
+            GPSCAL_HIP(ctx, ranks.alloc_async((size_t)W.total * maxlev, ctx->stream));
+            hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(W.mmax, GC_CHUNK), npairs), dim3(BLOCK), 0, ctx->stream,
+                               gs.pairs.p, gs.pts4.p, counts.p, ranks.p, W.total);
+            int rc = exclusive_scan(ctx, counts.p, gs.cell_start, cells + 1);
+            if (rc) return rc;
+            int gxf = std::max(1, std::min(div_up(W.mmax, BLOCK), 1024));
+            hipLaunchKernelGGL(grid_scatter_kernel, dim3(gxf, npairs), dim3(BLOCK), 0, ctx->stream, gs.pairs.p,
+                               gs.pts4.p, ranks.p, gs.cell_start, gs.sorted.p, W.total);
+            GPSCAL_HIP(ctx, hipGetLastError());
+        } else {
+            GPSCAL_HIP(ctx, hipMemsetAsync(gs.cell_start, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
         }
-    }
-    if (sorted_total >= (1ll << 32) - 1) return fail(ctx, GPSCAL_ERANGE, "batch too large for 32-bit cell offsets");
-    gs.total_cells = cells;
-    gs.total_sorted = sorted_total;
-    GPSCAL_HIP(ctx, gs.pooled ? gs.pairs.alloc_async(npairs, ctx->stream) : gs.pairs.alloc(npairs));
-    GPSCAL_HIP(ctx, hipMemcpyAsync(gs.pairs.p, gs.hpairs.data(), sizeof(PairDesc) * npairs, hipMemcpyHostToDevice,
-                                   ctx->stream));
-    DevBuf<unsigned> counts;
-    GPSCAL_HIP(ctx, counts.alloc_async((size_t)cells + 1, ctx->stream));
-    GPSCAL_HIP(ctx, gs.pooled ? gs.cell_start_buf.alloc_async((size_t)cells + 1 + 8, ctx->stream)
-                              : gs.cell_start_buf.alloc((size_t)cells + 1 + 8));
-    GPSCAL_HIP(ctx, hipMemsetAsync(gs.cell_start_buf.p, 0, sizeof(unsigned) * ((size_t)cells + 9), ctx->stream));
-    gs.cell_start = gs.cell_start_buf.p + 4;
-    GPSCAL_HIP(ctx, gs.pooled ? gs.sorted.alloc_async((size_t)sorted_total, ctx->stream) : gs.sorted.alloc((size_t)sorted_total));
-    GPSCAL_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
-    if (npairs > 0 && mmax > 0) {
-        int maxlev = 1;
-        for (auto &P : gs.hpairs) maxlev = std::max(maxlev, P.nlevels);
-        DevBuf<unsigned> ranks;
-        GPSCAL_HIP(ctx, ranks.alloc_async((size_t)total * maxlev, ctx->stream));
-        hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(mmax, GC_CHUNK), npairs), dim3(BLOCK), 0, ctx->stream,
-                           gs.pairs.p, gs.pts4.p, counts.p, ranks.p, total);
-        int rc = exclusive_scan(ctx, counts.p, gs.cell_start, cells + 1);
-        if (rc) return rc;
-        int gxf = std::max(1, std::min(div_up(mmax, BLOCK), 1024));
-        hipLaunchKernelGGL(grid_scatter_kernel, dim3(gxf, npairs), dim3(BLOCK), 0, ctx->stream, gs.pairs.p,
-                           gs.pts4.p, ranks.p, gs.cell_start, gs.sorted.p, total);
         GPSCAL_HIP(ctx, hipGetLastError());
-    } else {
-        GPSCAL_HIP(ctx, hipMemsetAsync(gs.cell_start, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
     }
-    GPSCAL_HIP(ctx, hipGetLastError());
-    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // a set with plain allocations is handed to callers that may use it from another stream
+    if (!all_pooled) GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GPSCAL_OK;
+}
+
+int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long long *off, int npairs, float cell,
+                int max_levels, GridSet &gs)
+{
+    const GridSource one = {xyz, off, npairs, &gs};
+    return build_grids_multi(ctx, 1, &one, stride, cell, max_levels);
 }
 
 // Neighbour lists and certified radii of every target point (ICP only; first use).

@@ -1195,16 +1195,15 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
     // the kd-trees of the last sweep (setInputCloud, LO:538-539,1119-1120) = two grid sets
     GridSet cg, sg;
     cg.pooled = sg.pooled = pool_grids();
-    int rc = build_grids(ctx, d_clast, 16, coff, nsweeps, 0.f, MAX_LEVELS, cg);
-    if (!rc) rc = build_grids(ctx, d_slast, 16, soff, nsweeps, 0.f, MAX_LEVELS, sg);
-    if (rc) return rc;
     // one more grid per ring of each last cloud for the adjacent-ring searches (LO:613-677, 769-844)
     GridSet rcg, rsg;
     rcg.pooled = rsg.pooled = pool_grids();
     DevBuf<int> d_ringc, d_rings;
     bool ring_grids = ring_cnt_c && ring_cnt_s;
+    std::vector<long long> roc, ros;
     if (ring_grids) {
-        std::vector<long long> roc((size_t)nsweeps * 16 + 1), ros((size_t)nsweeps * 16 + 1);
+        roc.resize((size_t)nsweeps * 16 + 1);
+        ros.resize((size_t)nsweeps * 16 + 1);
         for (int b = 0; b < nsweeps && ring_grids; ++b) {
             long long ac = coff[b], as = soff[b];
             for (int r = 0; r < 16; ++r) {
@@ -1217,15 +1216,21 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
         }
         roc[(size_t)nsweeps * 16] = coff[nsweeps];
         ros[(size_t)nsweeps * 16] = soff[nsweeps];
-        if (ring_grids) {
-            rc = build_grids(ctx, d_clast, 16, roc.data(), nsweeps * 16, 0.f, MAX_LEVELS, rcg);
-            if (!rc) rc = build_grids(ctx, d_slast, 16, ros.data(), nsweeps * 16, 0.f, MAX_LEVELS, rsg);
-            if (rc) return rc;
-            GPSCAL_HIP(ctx, d_ringc.alloc_async((size_t)nsweeps * 16, ctx->stream));
-            GPSCAL_HIP(ctx, d_rings.alloc_async((size_t)nsweeps * 16, ctx->stream));
-            GPSCAL_HIP(ctx, hipMemcpyAsync(d_ringc.p, ring_cnt_c, sizeof(int) * 16 * nsweeps, hipMemcpyHostToDevice, ctx->stream));
-            GPSCAL_HIP(ctx, hipMemcpyAsync(d_rings.p, ring_cnt_s, sizeof(int) * 16 * nsweeps, hipMemcpyHostToDevice, ctx->stream));
-        }
+    }
+    {
+        // all four index sets in one call: one host wait (their bounding boxes) instead of four
+        GridSource srcs[4] = {{d_clast, coff, nsweeps, &cg},
+                              {d_slast, soff, nsweeps, &sg},
+                              {d_clast, roc.data(), nsweeps * 16, &rcg},
+                              {d_slast, ros.data(), nsweeps * 16, &rsg}};
+        int rc = build_grids_multi(ctx, ring_grids ? 4 : 2, srcs, 16, 0.f, MAX_LEVELS);
+        if (rc) return rc;
+    }
+    if (ring_grids) {
+        GPSCAL_HIP(ctx, d_ringc.alloc_async((size_t)nsweeps * 16, ctx->stream));
+        GPSCAL_HIP(ctx, d_rings.alloc_async((size_t)nsweeps * 16, ctx->stream));
+        GPSCAL_HIP(ctx, hipMemcpyAsync(d_ringc.p, ring_cnt_c, sizeof(int) * 16 * nsweeps, hipMemcpyHostToDevice, ctx->stream));
+        GPSCAL_HIP(ctx, hipMemcpyAsync(d_rings.p, ring_cnt_s, sizeof(int) * 16 * nsweeps, hipMemcpyHostToDevice, ctx->stream));
     }
     // correspondence indices (ci1, ci2 | si1, si2, si3) live in one region per entry of `descs`: two
     // entries may name the same sweep (two replay passes of one bag at the same message)
@@ -1258,7 +1263,8 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
     hipLaunchKernelGGL(lo_finish_kernel, dim3(div_up(nsweeps, 64)), dim3(64), 0, ctx->stream, d_st.p, nsweeps, d_tr_out,
                        d_iters, d_nsel, d_sum_in, d_sum_out);
     GPSCAL_HIP(ctx, hipGetLastError());
-    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the grid sets die with this scope
+    // the grid sets die with this scope: pooled ones go back to the stream's block cache in stream order
+    if (!pool_grids()) GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GPSCAL_OK;
 }
 
@@ -1331,9 +1337,11 @@ int loam_mapping_device(gpscal_ctx *ctx, int nsweeps, const MapDesc *descs, cons
     // kdtreeCornerFromMap / kdtreeSurfFromMap (setInputCloud, LM:749-750) = two grid sets
     GridSet cg, sg;
     cg.pooled = sg.pooled = pool_grids();
-    int rc = build_grids(ctx, d_cmap, 16, cmoff, nsweeps, 0.f, MAX_LEVELS, cg);
-    if (!rc) rc = build_grids(ctx, d_smap, 16, smoff, nsweeps, 0.f, MAX_LEVELS, sg);
-    if (rc) return rc;
+    {
+        GridSource srcs[2] = {{d_cmap, cmoff, nsweeps, &cg}, {d_smap, smoff, nsweeps, &sg}};
+        int rc = build_grids_multi(ctx, 2, srcs, 16, 0.f, MAX_LEVELS);
+        if (rc) return rc;
+    }
     DevBuf<MapDesc> d_sw;
     DevBuf<IterState> d_st;
     DevBuf<double> d_part;
@@ -1363,7 +1371,7 @@ int loam_mapping_device(gpscal_ctx *ctx, int nsweeps, const MapDesc *descs, cons
     hipLaunchKernelGGL(iter_finish_kernel, dim3(div_up(nsweeps, 64)), dim3(64), 0, ctx->stream, d_st.p, nsweeps,
                        d_tr_out, d_iters, d_nsel);
     GPSCAL_HIP(ctx, hipGetLastError());
-    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!pool_grids()) GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // see loam_odometry_device
     return GPSCAL_OK;
 }
 
