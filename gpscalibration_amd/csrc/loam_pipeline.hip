@@ -798,6 +798,8 @@ struct LoamPipe {
     std::vector<int> frame_count;  // LO:495,1099-1127
     const double *h_stamps = nullptr;
 
+    // Every buffer of the chain is a block of the context stream's cache: a second run of the same shape takes
+    // them back without a single hipMalloc (the map pools alone are ~200 MB per stream of sweeps).
     int init(gpscal_ctx *c, int nstream_, const float *xyz, const int *sweep_off_, int nsw_, const double *stamps,
              int corner_cap, int surf_cap)
     {
@@ -810,13 +812,13 @@ struct LoamPipe {
         const size_t npts = (size_t)std::max(sweep_off[nsw], 1);
         GPSCAL_HIP(ctx, a_xyz.bind(ctx, xyz, npts * 3));
         DevBuf<float4> d_full;
-        GPSCAL_HIP(ctx, d_full.alloc(npts));
-        GPSCAL_HIP(ctx, d_sharp.alloc((size_t)nsw * 1536));
-        GPSCAL_HIP(ctx, d_lsharp.alloc((size_t)nsw * 1920));
-        GPSCAL_HIP(ctx, d_flat.alloc((size_t)nsw * 3072));
-        GPSCAL_HIP(ctx, d_lflat.alloc(npts));
-        GPSCAL_HIP(ctx, d_counts.alloc((size_t)nsw * 5));
-        GPSCAL_HIP(ctx, d_ring_counts.alloc((size_t)nsw * 32));
+        GPSCAL_HIP(ctx, d_full.alloc_async(npts, q));
+        GPSCAL_HIP(ctx, d_sharp.alloc_async((size_t)nsw * 1536, q));
+        GPSCAL_HIP(ctx, d_lsharp.alloc_async((size_t)nsw * 1920, q));
+        GPSCAL_HIP(ctx, d_flat.alloc_async((size_t)nsw * 3072, q));
+        GPSCAL_HIP(ctx, d_lflat.alloc_async(npts, q));
+        GPSCAL_HIP(ctx, d_counts.alloc_async((size_t)nsw * 5, q));
+        GPSCAL_HIP(ctx, d_ring_counts.alloc_async((size_t)nsw * 32, q));
         int sr_status = 0;
         int rc = scan_registration_device(ctx, nsw, sweep_off, sweep_off, a_xyz.dev, d_full.p, d_sharp.p, d_lsharp.p,
                                           d_flat.p, d_lflat.p, d_counts.p, &sr_status, d_ring_counts.p);
@@ -843,33 +845,33 @@ struct LoamPipe {
             dims.key_cap[t] = np2;
         }
         const int nseg = nstream;
-        GPSCAL_HIP(ctx, d_state.alloc(nseg));
+        GPSCAL_HIP(ctx, d_state.alloc_async(nseg, q));
         GPSCAL_HIP(ctx, hipMemsetAsync(d_state.p, 0, sizeof(SegState) * nseg, q));
         for (int t = 0; t < 2; ++t) {
             const size_t vcap = (size_t)dims.cap[t] + dims.stack_cap[t];
             for (int k = 0; k < 2; ++k) {
-                GPSCAL_HIP(ctx, b_pool[t][k].alloc((size_t)nseg * dims.cap[t]));
-                GPSCAL_HIP(ctx, b_ts[t][k].alloc((size_t)nseg * LNUM));
-                GPSCAL_HIP(ctx, b_tc[t][k].alloc((size_t)nseg * LNUM));
+                GPSCAL_HIP(ctx, b_pool[t][k].alloc_async((size_t)nseg * dims.cap[t], q));
+                GPSCAL_HIP(ctx, b_ts[t][k].alloc_async((size_t)nseg * LNUM, q));
+                GPSCAL_HIP(ctx, b_tc[t][k].alloc_async((size_t)nseg * LNUM, q));
                 GPSCAL_HIP(ctx, hipMemsetAsync(b_ts[t][k].p, 0, sizeof(int) * (size_t)nseg * LNUM, q));
                 GPSCAL_HIP(ctx, hipMemsetAsync(b_tc[t][k].p, 0, sizeof(int) * (size_t)nseg * LNUM, q));
                 B.pool[t][k] = b_pool[t][k].p;
                 B.tab_start[t][k] = b_ts[t][k].p;
                 B.tab_cnt[t][k] = b_tc[t][k].p;
             }
-            GPSCAL_HIP(ctx, b_frommap[t].alloc((size_t)nseg * dims.cap[t]));
-            GPSCAL_HIP(ctx, b_stack2[t].alloc((size_t)nseg * dims.stack_cap[t]));
-            GPSCAL_HIP(ctx, b_stack[t].alloc((size_t)nseg * dims.stack_cap[t]));
-            GPSCAL_HIP(ctx, b_newq[t].alloc((size_t)nseg * dims.stack_cap[t]));
-            GPSCAL_HIP(ctx, b_ns[t].alloc((size_t)nseg * LNUM));
-            GPSCAL_HIP(ctx, b_nc[t].alloc((size_t)nseg * LNUM));
-            GPSCAL_HIP(ctx, b_vin[t].alloc((size_t)nseg * vcap));
-            GPSCAL_HIP(ctx, b_vout[t].alloc((size_t)nseg * vcap));
-            GPSCAL_HIP(ctx, b_voff[t].alloc((size_t)nseg * MAXVALID));
-            GPSCAL_HIP(ctx, b_vcnt[t].alloc((size_t)nseg * MAXVALID));
-            GPSCAL_HIP(ctx, b_vocnt[t].alloc((size_t)nseg * MAXVALID));
-            GPSCAL_HIP(ctx, b_keys[t].alloc((size_t)nseg * dims.key_cap[t]));
-            GPSCAL_HIP(ctx, b_vkeys[t].alloc((size_t)nseg * 2 * vcap));
+            GPSCAL_HIP(ctx, b_frommap[t].alloc_async((size_t)nseg * dims.cap[t], q));
+            GPSCAL_HIP(ctx, b_stack2[t].alloc_async((size_t)nseg * dims.stack_cap[t], q));
+            GPSCAL_HIP(ctx, b_stack[t].alloc_async((size_t)nseg * dims.stack_cap[t], q));
+            GPSCAL_HIP(ctx, b_newq[t].alloc_async((size_t)nseg * dims.stack_cap[t], q));
+            GPSCAL_HIP(ctx, b_ns[t].alloc_async((size_t)nseg * LNUM, q));
+            GPSCAL_HIP(ctx, b_nc[t].alloc_async((size_t)nseg * LNUM, q));
+            GPSCAL_HIP(ctx, b_vin[t].alloc_async((size_t)nseg * vcap, q));
+            GPSCAL_HIP(ctx, b_vout[t].alloc_async((size_t)nseg * vcap, q));
+            GPSCAL_HIP(ctx, b_voff[t].alloc_async((size_t)nseg * MAXVALID, q));
+            GPSCAL_HIP(ctx, b_vcnt[t].alloc_async((size_t)nseg * MAXVALID, q));
+            GPSCAL_HIP(ctx, b_vocnt[t].alloc_async((size_t)nseg * MAXVALID, q));
+            GPSCAL_HIP(ctx, b_keys[t].alloc_async((size_t)nseg * dims.key_cap[t], q));
+            GPSCAL_HIP(ctx, b_vkeys[t].alloc_async((size_t)nseg * 2 * vcap, q));
             B.frommap[t] = b_frommap[t].p;
             B.stack2[t] = b_stack2[t].p;
             B.stack[t] = b_stack[t].p;
@@ -885,31 +887,31 @@ struct LoamPipe {
             B.vkeys[t] = b_vkeys[t].p;
         }
         for (int k = 0; k < NRING; ++k) {
-            GPSCAL_HIP(ctx, d_clast[k].alloc((size_t)nseg * max_ls));
-            GPSCAL_HIP(ctx, d_slast[k].alloc((size_t)nseg * max_lf));
-            GPSCAL_HIP(ctx, d_step_lo[k].alloc((size_t)nseg * 6));
+            GPSCAL_HIP(ctx, d_clast[k].alloc_async((size_t)nseg * max_ls, q));
+            GPSCAL_HIP(ctx, d_slast[k].alloc_async((size_t)nseg * max_lf, q));
+            GPSCAL_HIP(ctx, d_step_lo[k].alloc_async((size_t)nseg * 6, q));
             GPSCAL_HIP(ctx, hipMemsetAsync(d_step_lo[k].p, 0, sizeof(float) * 6 * nseg, q));
         }
-        GPSCAL_HIP(ctx, d_cmap.alloc((size_t)nseg * dims.cap[0]));
-        GPSCAL_HIP(ctx, d_smap.alloc((size_t)nseg * dims.cap[1]));
-        GPSCAL_HIP(ctx, d_cstack.alloc((size_t)nseg * dims.stack_cap[0]));
-        GPSCAL_HIP(ctx, d_sstack.alloc((size_t)nseg * dims.stack_cap[1]));
-        GPSCAL_HIP(ctx, d_post.alloc(nseg));
-        GPSCAL_HIP(ctx, d_prep.alloc(nseg));
-        GPSCAL_HIP(ctx, d_pack.alloc(nseg));
-        GPSCAL_HIP(ctx, d_rows.alloc(nseg));
-        GPSCAL_HIP(ctx, d_rows_o.alloc(nseg));
-        GPSCAL_HIP(ctx, d_sizes.alloc((size_t)nseg * 4));
-        GPSCAL_HIP(ctx, d_status.alloc(1));
-        GPSCAL_HIP(ctx, d_iters.alloc(nseg));
-        GPSCAL_HIP(ctx, d_nsel.alloc(nseg));
-        GPSCAL_HIP(ctx, d_tr.alloc((size_t)nseg * 6));
-        GPSCAL_HIP(ctx, d_tr2.alloc((size_t)nseg * 6));
-        GPSCAL_HIP(ctx, d_mtr.alloc((size_t)nseg * 6));
-        GPSCAL_HIP(ctx, d_mtr2.alloc((size_t)nseg * 6));
-        GPSCAL_HIP(ctx, d_step_stamp.alloc((size_t)nseg));
+        GPSCAL_HIP(ctx, d_cmap.alloc_async((size_t)nseg * dims.cap[0], q));
+        GPSCAL_HIP(ctx, d_smap.alloc_async((size_t)nseg * dims.cap[1], q));
+        GPSCAL_HIP(ctx, d_cstack.alloc_async((size_t)nseg * dims.stack_cap[0], q));
+        GPSCAL_HIP(ctx, d_sstack.alloc_async((size_t)nseg * dims.stack_cap[1], q));
+        GPSCAL_HIP(ctx, d_post.alloc_async(nseg, q));
+        GPSCAL_HIP(ctx, d_prep.alloc_async(nseg, q));
+        GPSCAL_HIP(ctx, d_pack.alloc_async(nseg, q));
+        GPSCAL_HIP(ctx, d_rows.alloc_async(nseg, q));
+        GPSCAL_HIP(ctx, d_rows_o.alloc_async(nseg, q));
+        GPSCAL_HIP(ctx, d_sizes.alloc_async((size_t)nseg * 4, q));
+        GPSCAL_HIP(ctx, d_status.alloc_async(1, q));
+        GPSCAL_HIP(ctx, d_iters.alloc_async(nseg, q));
+        GPSCAL_HIP(ctx, d_nsel.alloc_async(nseg, q));
+        GPSCAL_HIP(ctx, d_tr.alloc_async((size_t)nseg * 6, q));
+        GPSCAL_HIP(ctx, d_tr2.alloc_async((size_t)nseg * 6, q));
+        GPSCAL_HIP(ctx, d_mtr.alloc_async((size_t)nseg * 6, q));
+        GPSCAL_HIP(ctx, d_mtr2.alloc_async((size_t)nseg * 6, q));
+        GPSCAL_HIP(ctx, d_step_stamp.alloc_async((size_t)nseg, q));
         step_out_bytes = (size_t)nseg * (4 * sizeof(double) + 12 * sizeof(float) + sizeof(int));
-        GPSCAL_HIP(ctx, d_step_out.alloc(step_out_bytes));
+        GPSCAL_HIP(ctx, d_step_out.alloc_async(step_out_bytes, q));
         d_step_track = reinterpret_cast<double *>(d_step_out.p);
         d_step_lm = reinterpret_cast<float *>(d_step_track + (size_t)nseg * 4);
         d_step_tm = d_step_lm + (size_t)nseg * 6;
@@ -936,6 +938,8 @@ struct LoamPipe {
         hring_c.assign((size_t)nseg * 16, 0);
         hring_s.assign((size_t)nseg * 16, 0);
         frame_count.assign(nseg, 1);  // skipFrameNum, LO:495
+        // the odometry half may run on another stream: the fills above are done before it starts
+        GPSCAL_HIP(ctx, hipStreamSynchronize(q));
         return GPSCAL_OK;
     }
 
