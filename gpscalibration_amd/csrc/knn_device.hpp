@@ -135,6 +135,7 @@ struct Best {
         }
     }
     __device__ __forceinline__ float worst() const { return d[K - 1]; }
+    __device__ __forceinline__ bool seeded() const { return i[K - 1] != 0x7fffffff; }
     __device__ __forceinline__ void consider(float d2, const float4 &c, unsigned)
     {
         const int idx = __float_as_int(c.w);
@@ -180,6 +181,7 @@ struct BestQ {
     __device__ __forceinline__ float dist2() const { return __uint_as_float((unsigned)(key >> 32)); }
     __device__ __forceinline__ int index() const { return (int)(unsigned)key; }
     __device__ __forceinline__ float worst() const { return dist2(); }
+    __device__ __forceinline__ bool seeded() const { return index() != 0x7fffffff; }
     __device__ __forceinline__ void consider(float d2, const float4 &c, unsigned p)
     {
         const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(c.w);
@@ -213,6 +215,7 @@ struct BestRing {
         a0 = a0_; a1 = a1_; b0 = b0_; b1 = b1_;
     }
     __device__ __forceinline__ float worst() const { return d; }
+    __device__ __forceinline__ bool seeded() const { return i >= 0; }  // holds a candidate, not just the radius
     __device__ __forceinline__ void consider(float d2, const float4 &c, unsigned)
     {
         const int idx = __float_as_int(c.w) + base;
@@ -548,6 +551,47 @@ __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__res
                 }
             }
         }
+    }
+}
+
+// knn_query with one index PER LANE (`Pl`: the lane's pair descriptor; every lane passes a valid pointer, lanes
+// without a query pass act = false): the lanes of a wave search different clouds in one pass over the levels
+// instead of one pass per distinct cloud.  laserOdometry's adjacent-ring searches are the user: the 64 features
+// of a wave want 4-8 different rings, and a pass per ring made lo_search_kernel a chain of ~20 dependent
+// searches.  Fine -> coarse 3x3x3 search only (no ball search); the grid geometry lives in
+// vector registers instead of scalar ones, the candidates a lane sees are exactly those of knn_query.
+template <class BT>
+__device__ __forceinline__ void knn_query_lanes(const PairDesc *__restrict__ Pl, const float4 *__restrict__ sorted,
+                                                const unsigned *__restrict__ cell_start, bool act, float px, float py,
+                                                float pz, BT &B)
+{
+    if (!act) px = py = pz = 0.f;
+    const int nl = Pl->nlevels;
+    bool todo = act;
+    // A seed candidate's distance names the level to search: level l's 3x3x3 block holds every point within h_l
+    // (less the margin) of the query, so the first level with h_l >= that distance settles the query and the
+    // finer ones are skipped.
+    int lvl = 0;
+    {
+        const float w0 = B.worst();
+        if (w0 < INFINITY && B.seeded()) {  // a bare radius (laserOdometry's 5 m) would start at cells the size of it
+            lvl = nl - 1;
+            for (int l = MAX_LEVELS - 2; l >= 0; --l) {
+                if (l >= nl - 1) continue;
+                const float g = Pl->lv[l].h * 0.999f - Pl->lv[l].margin;
+                if (g > 0.f && w0 <= g * g) lvl = l;
+            }
+        }
+    }
+    for (int l = 0; l < MAX_LEVELS; ++l) {
+        if (__ballot(todo) == 0ull) break;
+        const bool a = todo && l < nl && l >= lvl;
+        if (__ballot(a) == 0ull) continue;
+        const GridDesc G = Pl->lv[min(l, nl - 1)];
+        CellGeo C;
+        C.set(G, px, py, pz);
+        block3_level(G, C, sorted, cell_start, a, px, py, pz, B);
+        if (a && (B.worst() <= C.settled_r2(G) || l == nl - 1)) todo = false;
     }
 }
 

@@ -288,12 +288,19 @@ __device__ __noinline__ bool solve_update(const double (&tot)[LSUMS], bool first
 }
 
 // Exact 1-NN of p in one indexed cloud (pair b of a GridSet); all lanes of the wave call it.
+// `seed` >= 0: a point of the cloud to start from (the previous search round's answer: the transform moved
+// the query only a little, so the search is down to one level and a few rows; the result is the exact nearest
+// neighbour either way).
 __device__ __forceinline__ void lo_nearest(const PairDesc &P, const float4 *__restrict__ sorted,
                                            const unsigned *__restrict__ cell_start, bool act, float4 p, int &idx,
-                                           float &sqd)
+                                           float &sqd, const float4 *__restrict__ cloud = nullptr, int seed = -1)
 {
     Best<1> B;
     B.init();
+    if (act && seed >= 0) {
+        const float4 c = cloud[seed];
+        B.consider(sqdist(p.x, p.y, p.z, c.x, c.y, c.z), make_float4(c.x, c.y, c.z, __int_as_float(seed)), 0u);
+    }
     knn_query(P, sorted, cell_start, act, p.x, p.y, p.z, B);
     idx = B.i[0] == 0x7fffffff ? -1 : B.i[0];
     sqd = B.d[0];
@@ -775,13 +782,21 @@ __device__ __forceinline__ void ring_search(const PairDesc *__restrict__ rp, con
                                             const unsigned *__restrict__ rcells, const int *rs, bool has, int want,
                                             float4 ps, BestRing &R)
 {
-    unsigned long long todo = __ballot(has && want >= 0 && want <= 15);
-    while (todo) {
-        const int r = __builtin_amdgcn_readlane(want, (int)__builtin_ctzll(todo));
-        const bool sel = has && want == r;
-        todo &= ~__ballot(sel);
-        R.base = rs[r];
-        knn_query(rp[r], rsorted, rcells, sel, ps.x, ps.y, ps.z, R);
+    // every lane searches the grid of the ring it wants, all of them in one pass (knn_query_lanes)
+    const bool sel = has && want >= 0 && want <= 15;
+    const int r = sel ? want : 0;
+    if (sel) R.base = rs[r];
+    knn_query_lanes(rp + r, rsorted, rcells, sel, ps.x, ps.y, ps.z, R);
+}
+
+// the previous round's answer as the first candidate of a ring search (it still has to pass the record's
+// interval filter: the closest point, and with it the rings, may have changed)
+__device__ __forceinline__ void ring_seed(BestRing &R, bool has, const float4 *__restrict__ cloud, int seed, float4 ps)
+{
+    if (has && seed >= 0) {
+        const float4 c = cloud[seed];
+        R.base = 0;
+        R.consider(sqdist(ps.x, ps.y, ps.z, c.x, c.y, c.z), make_float4(c.x, c.y, c.z, __int_as_float(seed)), 0u);
     }
 }
 
@@ -826,7 +841,8 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
         const float4 ps = lo_to_start(tr, pi);
         int idx;
         float sqd;
-        lo_nearest(CP, csorted, ccells, act, ps, idx, sqd);
+        const int prev1 = act ? ci1[i] : -1, prev2 = act ? ci2[i] : -1;  // -1 in a sweep's first round (lo_init_kernel)
+        lo_nearest(CP, csorted, ccells, act, ps, idx, sqd, cl, prev1);
         int closest = -1, min2 = -1;
         const bool has = act && idx >= 0 && sqd < 25;
         if (has) closest = idx;
@@ -843,6 +859,7 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
             }
             BestRing R;
             R.init(25.f, closest, a0, a1, b0, b1);
+            ring_seed(R, has, cl, prev2, ps);
             if (ring_grids) {
                 const int scan = has ? (int)cl[closest].w : -9;
                 ring_search(rcpairs + 16 * b, rcsorted, rccells, s_rs_c, has && a1 > a0, scan - 1, ps, R);
@@ -909,7 +926,8 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
         const float4 ps = lo_to_start(tr, pi);
         int idx;
         float sqd;
-        lo_nearest(SP, ssorted, scells, act, ps, idx, sqd);
+        const int prev1 = act ? si1[i] : -1, prev2 = act ? si2[i] : -1, prev3 = act ? si3[i] : -1;
+        lo_nearest(SP, ssorted, scells, act, ps, idx, sqd, sl, prev1);
         int closest = -1, min2 = -1, min3 = -1;
         const bool has = act && idx >= 0 && sqd < 25;
         if (has) closest = idx;
@@ -931,6 +949,8 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
             BestRing R2, R3;
             R2.init(25.f, closest, a0, a1, b0, b1);
             R3.init(25.f, closest, c0, c1, e0, e1);
+            ring_seed(R2, has, sl, prev2, ps);
+            ring_seed(R3, has, sl, prev3, ps);
             if (ring_grids) {
                 const int scan = has ? (int)sl[closest].w : -9;
                 ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && (a1 > a0 || b1 > b0), scan, ps, R2);

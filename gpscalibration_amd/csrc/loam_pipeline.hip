@@ -740,6 +740,10 @@ using namespace gpscal;
 
 namespace {
 
+#ifndef GPSCAL_LOAM_RING
+#define GPSCAL_LOAM_RING 4  // measured at 6 segments: 3 / 4 / 6 slots = 2 170 / 2 230 / 2 235 sweeps/s
+#endif
+
 // GPSCAL_LOAM_PIPELINE=0: gpscal_loam_run_batched runs the two halves of a step one after the other again
 inline bool loam_pipelined()
 {
@@ -754,6 +758,9 @@ inline bool loam_pipelined()
 // sweeps are registered (scanRegistration) up front; a step names, per stream, which sweep is
 // published next (or none), and returns what the stream's nodes emitted for it.
 struct LoamPipe {
+    // ring of hand-over slots between the two halves of a step: laserOdometry may run NRING - 1 sweeps ahead of
+    // transformMaintenance + laserMapping (which does its work in bursts, on every second sweep)
+    static constexpr int NRING = GPSCAL_LOAM_RING;
     gpscal_ctx *ctx = nullptr;
     int nstream = 0, nsw = 0;
     const int *sweep_off = nullptr;
@@ -771,12 +778,12 @@ struct LoamPipe {
     DevBuf<float4> b_pool[2][2], b_frommap[2], b_stack2[2], b_stack[2], b_newq[2], b_vin[2], b_vout[2];
     DevBuf<int> b_ts[2][2], b_tc[2][2], b_ns[2], b_nc[2], b_voff[2], b_vcnt[2], b_vocnt[2];
     DevBuf<unsigned long long> b_keys[2], b_vkeys[2];
-    DevBuf<float4> d_clast[3], d_slast[3], d_cmap, d_smap, d_cstack, d_sstack;  // [NRING]
+    DevBuf<float4> d_clast[NRING], d_slast[NRING], d_cmap, d_smap, d_cstack, d_sstack;
     DevBuf<PostDesc> d_post;
     DevBuf<PrepDesc> d_prep;
     DevBuf<PackDesc> d_pack;
     DevBuf<int> d_rows, d_rows_o, d_sizes, d_status, d_iters, d_nsel;
-    DevBuf<float> d_tr, d_tr2, d_mtr, d_mtr2, d_step_lo[3];  // odometry / mapping scratch; [NRING]
+    DevBuf<float> d_tr, d_tr2, d_mtr, d_mtr2, d_step_lo[NRING];  // odometry / mapping scratch
     DevBuf<double> d_step_stamp;
     // the mapping half's per-step outputs in one block (one fill, one read-back per step): track | lm | tm | iterations
     DevBuf<char> d_step_out;
@@ -955,7 +962,6 @@ struct LoamPipe {
         bool any_tm = false, any_map = false;
         int buf = 0;
     };
-    static constexpr int NRING = 3;  // laserOdometry may run two sweeps ahead of laserMapping (sizes of d_clast ...)
     StepSlot slots[NRING];
     long long step_no = 0;  // steps started by step_odo
 
