@@ -747,11 +747,8 @@ namespace {
 // GPSCAL_LOAM_PIPELINE=0: gpscal_loam_run_batched runs the two halves of a step one after the other again
 inline bool loam_pipelined()
 {
-    static const bool on = [] {
-        const char *e = getenv("GPSCAL_LOAM_PIPELINE");
-        return e ? atoi(e) != 0 : true;
-    }();
-    return on;
+    const char *e = getenv("GPSCAL_LOAM_PIPELINE");  // read per call: the tests compare both orders in one process
+    return e ? atoi(e) != 0 : true;
 }
 
 // The node chain for `nstream` independent streams of sweeps, advanced one sweep per step.  All

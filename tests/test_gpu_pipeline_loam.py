@@ -54,6 +54,18 @@ def test_loam_run_two_segments_match_oracle(ctx):
         del os.environ["GPSCAL_LOAM_GROUP"]
     for g, h in zip(got, one_by_one):
         assert all(np.array_equal(g[k], h[k], equal_nan=True) for k in g)
+    # laserOdometry running ahead of laserMapping on its own stream (the default) gives the bits of the
+    # lock-step order, in which every step's two halves run one after the other on one stream
+    os.environ["GPSCAL_LOAM_PIPELINE"] = "0"
+    try:
+        lock_step = ctx.loam_run([sw_a, sw_b], [st_a, st_b])
+    finally:
+        del os.environ["GPSCAL_LOAM_PIPELINE"]
+    for g, h in zip(got, lock_step):
+        assert all(np.array_equal(g[k], h[k], equal_nan=True) for k in g)
+    again = ctx.loam_run([sw_a, sw_b], [st_a, st_b])  # and is reproducible from run to run
+    for g, h in zip(got, again):
+        assert all(np.array_equal(g[k], h[k], equal_nan=True) for k in g)
     ref_a, ref_b = O.loam_run(sw_a, st_a), O.loam_run(sw_b, st_b)
     _check(got[0], ref_a, 30)
     _check(got[1], ref_b, 21)
