@@ -782,9 +782,9 @@ struct LoamPipe {
     DevBuf<int> d_rows, d_rows_o, d_sizes, d_status, d_iters, d_nsel;
     DevBuf<float> d_tr, d_tr2, d_mtr, d_mtr2, d_step_lo[NRING];  // odometry / mapping scratch
     DevBuf<double> d_step_stamp;
-    // the mapping half's per-step outputs in one block (one fill, one read-back per step): track | lm | tm | iterations
+    // the mapping half's per-step outputs in one block (one fill per step): track | tm | lm | iterations
     DevBuf<char> d_step_out;
-    size_t step_out_bytes = 0;
+    size_t step_out_bytes = 0, tm_out_bytes = 0;
     double *d_step_track = nullptr;
     float *d_step_lm = nullptr, *d_step_tm = nullptr;
     int *d_step_it = nullptr;
@@ -917,9 +917,10 @@ struct LoamPipe {
         step_out_bytes = (size_t)nseg * (4 * sizeof(double) + 12 * sizeof(float) + sizeof(int));
         GPSCAL_HIP(ctx, d_step_out.alloc_async(step_out_bytes, q));
         d_step_track = reinterpret_cast<double *>(d_step_out.p);
-        d_step_lm = reinterpret_cast<float *>(d_step_track + (size_t)nseg * 4);
-        d_step_tm = d_step_lm + (size_t)nseg * 6;
-        d_step_it = reinterpret_cast<int *>(d_step_tm + (size_t)nseg * 6);
+        d_step_tm = reinterpret_cast<float *>(d_step_track + (size_t)nseg * 4);
+        d_step_lm = d_step_tm + (size_t)nseg * 6;
+        d_step_it = reinterpret_cast<int *>(d_step_lm + (size_t)nseg * 6);
+        tm_out_bytes = (size_t)nseg * (4 * sizeof(double) + 6 * sizeof(float));  // track | tm: transformMaintenance's part
         h_step_out.resize(step_out_bytes);
         GPSCAL_HIP(ctx, hipMemsetAsync(d_status.p, 0, sizeof(int), q));
         hpost.resize(nseg);
@@ -1073,9 +1074,38 @@ struct LoamPipe {
         return GPSCAL_OK;
     }
 
-    // Mapping half of a step, on ctx->stream: transformMaintenance, laserMapping (every second published
-    // sweep) and the step's host outputs (nstream rows each): lo / lm / tm poses, track, iterations.
-    int step_map(const StepSlot &L, float *lo, float *lm, float *tm, double *track, int *iters)
+    // transformMaintenance's part of a step, on ctx->stream (TM:267-314, 113-157): needs the step's odometry and the
+    // LAST mapping cycle's correction only, so the step's track sample is known before its own mapping cycle runs --
+    // which is what lets input_data's cut decision (it reads the track) be taken while laserMapping still works.
+    // Host outputs, nstream rows each (may be null): tm poses, track.  Synchronises the stream.
+    int step_tm(const StepSlot &L, float *tm, double *track)
+    {
+        auto t0 = clk::now();
+        hipStream_t q = ctx->stream;
+        const int nseg = nstream;
+        SegState *S = d_state.p;
+        GPSCAL_HIP(ctx, hipMemsetAsync(d_step_out.p, 0xff, step_out_bytes, q));  // track | tm | lm | iterations
+        if (L.any_tm) {
+            GPSCAL_HIP(ctx, hipMemcpyAsync(d_rows.p, L.rows_tm.data(), sizeof(int) * nseg, hipMemcpyHostToDevice, q));
+            GPSCAL_HIP(ctx, hipMemcpyAsync(d_step_stamp.p, L.stamp.data(), sizeof(double) * nseg, hipMemcpyHostToDevice, q));
+            hipLaunchKernelGGL(tm_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, d_rows.p, d_step_stamp.p, nseg,
+                               d_step_lo[L.buf].p, d_step_tm, d_step_track);
+            GPSCAL_HIP(ctx, hipGetLastError());
+        }
+        if (tm || track) {
+            GPSCAL_HIP(ctx, hipMemcpyAsync(h_step_out.data(), d_step_out.p, tm_out_bytes, hipMemcpyDeviceToHost, q));
+            GPSCAL_HIP(ctx, hipStreamSynchronize(q));
+            const char *h = h_step_out.data();
+            if (track) memcpy(track, h, sizeof(double) * 4 * nseg);
+            if (tm) memcpy(tm, h + sizeof(double) * 4 * nseg, sizeof(float) * 6 * nseg);
+        }
+        t_add(2, t0);
+        return GPSCAL_OK;
+    }
+
+    // laserMapping's part of a step, on ctx->stream (LM:420-1079, every second published sweep), after step_tm of
+    // the same step.  Host outputs (may be null): lo / lm poses, iterations.  Synchronises the stream.
+    int step_mapping(const StepSlot &L, float *lo, float *lm, int *iters)
     {
         auto t0 = clk::now();
         hipStream_t q = ctx->stream;
@@ -1084,14 +1114,6 @@ struct LoamPipe {
         const int buf = L.buf;
         const size_t lds_keys = sizeof(unsigned long long) * LDS_KEYS;
         const std::vector<long long> &coff = L.coff, &soff = L.soff;
-        GPSCAL_HIP(ctx, hipMemsetAsync(d_step_out.p, 0xff, step_out_bytes, q));  // lm | tm | track | iterations
-        if (L.any_tm) {
-            GPSCAL_HIP(ctx, hipMemcpyAsync(d_rows.p, L.rows_tm.data(), sizeof(int) * nseg, hipMemcpyHostToDevice, q));
-            GPSCAL_HIP(ctx, hipMemcpyAsync(d_step_stamp.p, L.stamp.data(), sizeof(double) * nseg, hipMemcpyHostToDevice, q));
-            hipLaunchKernelGGL(tm_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, d_rows.p, d_step_stamp.p, nseg,
-                               d_step_lo[buf].p, d_step_tm, d_step_track);
-            GPSCAL_HIP(ctx, hipGetLastError());
-        }
         if (L.any_map) {
             for (int s = 0; s < nseg; ++s) {
                 PrepDesc &P = hprep[s];
@@ -1148,19 +1170,26 @@ struct LoamPipe {
         }
         t_add(4, t0);
         t0 = clk::now();
-        // one read-back for the step: lm | tm | track | iterations, then laserOdometry's transformSum
-        GPSCAL_HIP(ctx, hipMemcpyAsync(h_step_out.data(), d_step_out.p, step_out_bytes, hipMemcpyDeviceToHost, q));
+        if (lm || iters)
+            GPSCAL_HIP(ctx, hipMemcpyAsync(h_step_out.data() + tm_out_bytes, d_step_out.p + tm_out_bytes,
+                                           step_out_bytes - tm_out_bytes, hipMemcpyDeviceToHost, q));
         if (lo) GPSCAL_HIP(ctx, hipMemcpyAsync(lo, d_step_lo[buf].p, sizeof(float) * 6 * nseg, hipMemcpyDeviceToHost, q));
         GPSCAL_HIP(ctx, hipStreamSynchronize(q));
         {
-            const char *h = h_step_out.data();
-            if (lm) memcpy(lm, h + ((const char *)d_step_lm - (const char *)d_step_out.p), sizeof(float) * 6 * nseg);
-            if (tm) memcpy(tm, h + ((const char *)d_step_tm - (const char *)d_step_out.p), sizeof(float) * 6 * nseg);
-            if (iters) memcpy(iters, h + ((const char *)d_step_it - (const char *)d_step_out.p), sizeof(int) * nseg);
-            memcpy(track, h + ((const char *)d_step_track - (const char *)d_step_out.p), sizeof(double) * 4 * nseg);
+            const char *h = h_step_out.data() + tm_out_bytes;
+            if (lm) memcpy(lm, h, sizeof(float) * 6 * nseg);
+            if (iters) memcpy(iters, h + sizeof(float) * 6 * nseg, sizeof(int) * nseg);
         }
         t_add(5, t0);
         return GPSCAL_OK;
+    }
+
+    // Mapping half of a step: both parts.
+    int step_map(const StepSlot &L, float *lo, float *lm, float *tm, double *track, int *iters)
+    {
+        int rc = step_tm(L, tm, track);
+        if (rc) return rc;
+        return step_mapping(L, lo, lm, iters);
     }
 
     // One sweep per stream (sweep_idx[s] < 0: the stream idles), both halves one after the other on the
@@ -1429,6 +1458,83 @@ extern "C" int gpscal_input_data_run(gpscal_ctx *ctx, int nbag, const float *xyz
         }
         S.phase = 2;
     };
+    // The nodes run concurrently here too, as far as input_data's feedback allows: a step's cut decisions read its
+    // /true_odometry_to_init sample, which transformMaintenance computes from the step's odometry and the PREVIOUS
+    // mapping cycle -- so the mapping cycle of step t (a worker thread, the context's stream) overlaps laserOdometry of
+    // step t + 1 (this thread, its own stream).  The order of every node's inputs is that of the lock-step replay.
+    struct Mapper {
+        bool on = false;
+        LoamPipe *P = nullptr;
+        gpscal_ctx octx;
+        hipStream_t os = nullptr;
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        const LoamPipe::StepSlot *job = nullptr;
+        bool busy = false, quit = false;
+        int rc = 0;
+        void run()
+        {
+            (void)hipSetDevice(P->ctx->device);
+            for (;;) {
+                const LoamPipe::StepSlot *j;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return quit || job; });
+                    if (!job) return;
+                    j = job;
+                }
+                const int r = P->step_mapping(*j, nullptr, nullptr, nullptr);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (r && !rc) rc = r;
+                    job = nullptr;
+                    busy = false;
+                }
+                cv.notify_all();
+            }
+        }
+        void post(const LoamPipe::StepSlot *j)
+        {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                job = j;
+                busy = true;
+            }
+            cv.notify_all();
+        }
+        int wait()  // until the worker is idle; its first error, if any
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !busy; });
+            return rc;
+        }
+        ~Mapper()
+        {
+            if (th.joinable()) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !busy; });
+                    quit = true;
+                }
+                cv.notify_all();
+                th.join();
+            }
+            if (os) {
+                (void)hipStreamSynchronize(os);
+                cache_trim(os);
+                (void)hipStreamDestroy(os);
+            }
+        }
+    } mapper;
+    if (loam_pipelined()) {
+        mapper.P = &P;
+        mapper.octx = *ctx;
+        GPSCAL_HIP(ctx, hipStreamCreateWithFlags(&mapper.os, hipStreamNonBlocking));
+        mapper.octx.stream = mapper.os;
+        mapper.th = std::thread([&mapper] { mapper.run(); });
+        mapper.on = true;
+    }
     for (;;) {
         bool any = false;
         for (int s = 0; s < nstream; ++s) {
@@ -1447,8 +1553,28 @@ extern "C" int gpscal_input_data_run(gpscal_ctx *ctx, int nbag, const float *xyz
             any = true;
         }
         if (!any) break;
-        rc = P.step(idx.data(), pub.data(), mapd.data(), nullptr, nullptr, nullptr, tr.data(), nullptr);
-        if (rc) return rc;
+        if (!mapper.on) {
+            rc = P.step(idx.data(), pub.data(), mapd.data(), nullptr, nullptr, nullptr, tr.data(), nullptr);
+            if (rc) return rc;
+        } else {
+            // laserOdometry of this step (own stream) while the worker still runs the previous step's mapping cycle;
+            // transformMaintenance needs both, and the step's cut decisions need only its track sample
+            LoamPipe::StepSlot &L = P.slots[P.step_no % LoamPipe::NRING];
+            rc = P.step_odo(&mapper.octx, idx.data(), L);
+            int rc_w = mapper.wait();
+            if (rc) {
+                ctx->last_error = mapper.octx.last_error;
+                return rc;
+            }
+            if (rc_w) return rc_w;
+            rc = P.step_tm(L, nullptr, tr.data());
+            if (rc) return rc;
+            for (int s = 0; s < nstream; ++s) {
+                pub[s] = L.published[s];
+                mapd[s] = L.do_map[s];
+            }
+            if (L.any_map) mapper.post(&L);
+        }
         for (int s = 0; s < nstream; ++s) {
             Stream &S = st[s];
             if (idx[s] < 0) continue;
@@ -1477,6 +1603,10 @@ extern "C" int gpscal_input_data_run(gpscal_ctx *ctx, int nbag, const float *xyz
                 close_track(S, s, true);
             }
         }
+    }
+    if (mapper.on) {
+        rc = mapper.wait();
+        if (rc) return rc;
     }
     rc = P.finish();
     if (rc) return rc;

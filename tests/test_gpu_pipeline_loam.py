@@ -121,6 +121,19 @@ def test_input_data_segmentation_matches_oracle(ctx):
                 ref.append(dict(t, flag=flag, bag=b))
     assert [(t["flag"], t["bag"], t["first"], t["last"]) for t in got] == \
            [(t["flag"], t["bag"], t["first"], t["last"]) for t in ref]
+    # the default overlaps a step's mapping cycle with the next step's laserOdometry (worker thread, two streams):
+    # same bits as every node one after the other on one stream
+    import os
+    os.environ["GPSCAL_LOAM_PIPELINE"] = "0"
+    try:
+        lock_step = ctx.input_data_run([bag_a, bag_b], [st_a, st_b], L, S, OV, corner_pool_cap=1 << 16,
+                                       surf_pool_cap=1 << 18)
+    finally:
+        del os.environ["GPSCAL_LOAM_PIPELINE"]
+    assert len(lock_step) == len(got)
+    for g, h in zip(got, lock_step):
+        assert (g["flag"], g["bag"], g["first"], g["last"]) == (h["flag"], h["bag"], h["first"], h["last"])
+        assert np.array_equal(g["track"], h["track"], equal_nan=True)
     for g, r in zip(got, ref):
         assert g["track"].shape == r["track"].shape
         assert np.abs(g["track"][:, :2] - r["track"][:, :2]).max() < 2e-2
