@@ -930,8 +930,19 @@ struct gpscal_scan_batch {
     DevBuf<double> partials, pose64, err_hist;
     DevBuf<float> pose32;
     int err_cap = 0;
-    hipGraphExec_t graph = nullptr;
-    int graph_iters = 0;
+    // captured graphs by iteration count (callers that alternate between two counts keep both)
+    static constexpr int NGRAPH = 4;
+    hipGraphExec_t graphs[NGRAPH] = {};
+    int graph_iters[NGRAPH] = {};
+    unsigned graph_used[NGRAPH] = {}, graph_clock = 0;
+    void drop_graphs()
+    {
+        for (int k = 0; k < NGRAPH; ++k)
+            if (graphs[k]) {
+                (void)hipGraphExecDestroy(graphs[k]);
+                graphs[k] = nullptr;
+            }
+    }
     double build_seconds = 0.0;
     // independent step -> solve chains of the captured graph (launch_step)
     static constexpr int MAX_CHAINS = 8;
@@ -941,7 +952,7 @@ struct gpscal_scan_batch {
     hipEvent_t chain_ev[MAX_CHAINS] = {};
     ~gpscal_scan_batch()
     {
-        if (graph) (void)hipGraphExecDestroy(graph);
+        drop_graphs();
         if (tgt && !borrowed) delete tgt;
     }
 };
@@ -1261,10 +1272,7 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
     GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
     const int np = B->npairs;
     if (iters > B->err_cap) {
-        if (B->graph) {
-            (void)hipGraphExecDestroy(B->graph);
-            B->graph = nullptr;
-        }
+        B->drop_graphs();  // they hold the old error-history pointer
         GPSCAL_HIP(ctx, B->err_hist.alloc((size_t)np * iters));
         B->err_cap = iters;
     }
@@ -1286,10 +1294,21 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
         for (int it = 0; it < iters; ++it) GPSCAL_HIP(ctx, hipEventElapsedTime(&step_ms[it], ev[2 * it], ev[2 * it + 1]));
         for (auto &e : ev) (void)hipEventDestroy(e);
     } else if (iters > 0) {
-        if (!B->graph || B->graph_iters != iters) {
-            if (B->graph) {
-                (void)hipGraphExecDestroy(B->graph);
-                B->graph = nullptr;
+        int slot = -1;
+        for (int k = 0; k < gpscal_scan_batch::NGRAPH; ++k)
+            if (B->graphs[k] && B->graph_iters[k] == iters) slot = k;
+        if (slot < 0) {
+            slot = 0;  // an empty slot, else the least recently used one
+            for (int k = 0; k < gpscal_scan_batch::NGRAPH; ++k) {
+                if (!B->graphs[k]) {
+                    slot = k;
+                    break;
+                }
+                if (B->graph_used[k] < B->graph_used[slot]) slot = k;
+            }
+            if (B->graphs[slot]) {
+                (void)hipGraphExecDestroy(B->graphs[slot]);
+                B->graphs[slot] = nullptr;
             }
             hipGraph_t g = nullptr;
             // chain 0 on the context's stream, the others on side streams forked from / joined to it
@@ -1309,11 +1328,12 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
                 GPSCAL_HIP(ctx, hipStreamWaitEvent(ctx->stream, B->chain_ev[c], 0));
             }
             GPSCAL_HIP(ctx, hipStreamEndCapture(ctx->stream, &g));
-            GPSCAL_HIP(ctx, hipGraphInstantiate(&B->graph, g, nullptr, nullptr, 0));
+            GPSCAL_HIP(ctx, hipGraphInstantiate(&B->graphs[slot], g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
-            B->graph_iters = iters;
+            B->graph_iters[slot] = iters;
         }
-        GPSCAL_HIP(ctx, hipGraphLaunch(B->graph, ctx->stream));
+        B->graph_used[slot] = ++B->graph_clock;
+        GPSCAL_HIP(ctx, hipGraphLaunch(B->graphs[slot], ctx->stream));
     }
     bool sync = false;
     if (T_out) {
