@@ -134,6 +134,16 @@ struct Best {
             i[k] = 0x7fffffff;
         }
     }
+    // only candidates closer than sqrt(r2) count: a query with fewer than K of them stops climbing at the level
+    // that covers the radius instead of the coarsest one (the caller discards results at or beyond r2 anyway)
+    __device__ __forceinline__ void init_radius(float r2)
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            d[k] = r2;
+            i[k] = 0x7fffffff;
+        }
+    }
     __device__ __forceinline__ float worst() const { return d[K - 1]; }
     __device__ __forceinline__ bool seeded() const { return i[K - 1] != 0x7fffffff; }
     __device__ __forceinline__ void consider(float d2, const float4 &c, unsigned)
@@ -503,7 +513,9 @@ __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__res
     bool todo = act;
     {
         const float w0 = B.worst();
-        if (BT::WARM_START && w0 < INFINITY) {
+        // (a record that starts with a bare radius -- no candidate yet -- still climbs from level 0: the fine
+        // levels usually settle it with far fewer candidates than the level of the radius holds)
+        if (BT::WARM_START && w0 < INFINITY && B.seeded()) {
             if (ballmode) todo = false;
             lvl = P.nlevels - 1;
             for (int l = P.nlevels - 2; l >= 0; --l) {

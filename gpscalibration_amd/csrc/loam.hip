@@ -296,7 +296,7 @@ __device__ __forceinline__ void lo_nearest(const PairDesc &P, const float4 *__re
                                            float &sqd, const float4 *__restrict__ cloud = nullptr, int seed = -1)
 {
     Best<1> B;
-    B.init();
+    B.init_radius(25.f);  // LO:607,758: a nearest point at 5 m or more is no correspondence
     if (act && seed >= 0) {
         const float4 c = cloud[seed];
         B.consider(sqdist(p.x, p.y, p.z, c.x, c.y, c.z), make_float4(c.x, c.y, c.z, __int_as_float(seed)), 0u);
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(PT_BLOCK) void lm_point_kernel(
         if (act) po = cs[i];
         const float4 ps = lm_to_map(g, po);
         Best<5> B;
-        B.init();
+        B.init_radius(1.0f);  // LM:762,865: a feature whose fifth neighbour is not within 1 m is dropped
         // last iteration's five neighbours first: the transform moved the query only a little, so they
         // bound the search to one grid level (the result is the exact k-NN either way)
         int *pv = prev5 + 5 * (D.cstack_off + i);
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(PT_BLOCK) void lm_point_kernel(
         if (act) po = ss[i];
         const float4 ps = lm_to_map(g, po);
         Best<5> B;
-        B.init();
+        B.init_radius(1.0f);  // LM:762,865: a feature whose fifth neighbour is not within 1 m is dropped
         int *pv = prev5 + 5 * (surf_base + D.sstack_off + i);  // the surf entries follow the corner entries
         if (act && pv[0] >= 0) {
 #pragma unroll
