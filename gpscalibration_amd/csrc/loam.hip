@@ -26,7 +26,10 @@
 
 namespace gpscal {
 
-constexpr int LBLOCK = 512;
+#ifndef GPSCAL_LO_DIAG
+#define GPSCAL_LO_DIAG 0  // ablations of lo_search_kernel (wrong results): 1 = no ring searches, 2 = no nearest search
+#endif
+constexpr int LBLOCK = 512;  // 1024 threads: 2 340 against 2 900 sweeps/s (the register cap of a 16-wave workgroup costs more than the shorter point loop gives)
 constexpr int LWAVES = LBLOCK / 64;
 constexpr int LSUMS = 28;  // 21 upper-triangle AtA + 6 AtB + 1 row count
 constexpr int RS = 8;       // ring-walk candidates fetched per step
@@ -301,7 +304,7 @@ __device__ __forceinline__ void lo_nearest(const PairDesc &P, const float4 *__re
         const float4 c = cloud[seed];
         B.consider(sqdist(p.x, p.y, p.z, c.x, c.y, c.z), make_float4(c.x, c.y, c.z, __int_as_float(seed)), 0u);
     }
-    knn_query(P, sorted, cell_start, act, p.x, p.y, p.z, B);
+    if (!(GPSCAL_LO_DIAG & 2)) knn_query(P, sorted, cell_start, act, p.x, p.y, p.z, B);
     idx = B.i[0] == 0x7fffffff ? -1 : B.i[0];
     sqd = B.d[0];
 }
@@ -782,6 +785,7 @@ __device__ __forceinline__ void ring_search(const PairDesc *__restrict__ rp, con
                                             const unsigned *__restrict__ rcells, const int *rs, bool has, int want,
                                             float4 ps, BestRing &R)
 {
+    if (GPSCAL_LO_DIAG & 1) return;
     // every lane searches the grid of the ring it wants, all of them in one pass (knn_query_lanes)
     const bool sel = has && want >= 0 && want <= 15;
     const int r = sel ? want : 0;
@@ -825,6 +829,9 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     __syncthreads();
     const bool mono = st[b].mono != 0;
     const bool ring_grids = rcpairs != nullptr && st[b].ring_ok != 0;
+    STAT_WAVE(2, 1);  // waves of lo_search_kernel
+    STAT_WAVE(21, mono ? 1 : 0);
+    STAT_WAVE(22, ring_grids ? 1 : 0);
     const PairDesc &CP = cpairs[b];
     const PairDesc &SP = spairs[b];
     const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off, *cl = clast + D.clast_off,
@@ -1205,6 +1212,20 @@ __global__ void loam_to_end_kernel(const float *__restrict__ tr6, const float4 *
 
 using namespace gpscal;
 
+#ifdef GPSCAL_STATS
+__global__ void loam_stat_slot_kernel(int slot) { g_stat_iter = slot; }
+// instrumented builds only: the search counters of this translation unit (slot 1 = lo_search_kernel, 2 = lm_point_kernel)
+extern "C" int gpscal_debug_stats_loam(unsigned long long *out, int n)
+{
+    std::vector<unsigned long long> h(NSTAT * STAT_ITERS, 0ull);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stats), h.size() * 8) != hipSuccess) return GPSCAL_EHIP;
+    for (int i = 0; i < n && i < (int)h.size(); ++i) out[i] = h[i];
+    std::fill(h.begin(), h.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stats), h.data(), h.size() * 8) != hipSuccess) return GPSCAL_EHIP;
+    return GPSCAL_OK;
+}
+#endif
+
 namespace gpscal {
 
 int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, const float4 *d_sharp,
@@ -1272,6 +1293,9 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
     GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, descs, sizeof(SweepDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(lo_init_kernel, dim3(nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_clast, d_slast, corr.p,
                        d_tr_in, d_st.p, ring_grids ? d_ringc.p : nullptr, ring_grids ? d_rings.p : nullptr);
+#ifdef GPSCAL_STATS
+    hipLaunchKernelGGL(loam_stat_slot_kernel, dim3(1), dim3(1), 0, ctx->stream, 1);
+#endif
     for (int it0 = 0; it0 < 25; it0 += 5) {  // LO:585: a search every fifth iteration (LO:592)
         hipLaunchKernelGGL(lo_search_kernel, dim3(tiles_max, nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_sharp,
                            d_flat, d_clast, d_slast, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p,
@@ -1381,6 +1405,9 @@ int loam_mapping_device(gpscal_ctx *ctx, int nsweeps, const MapDesc *descs, cons
     GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, descs, sizeof(MapDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(lm_init_kernel, dim3(div_up(nsweeps, 64)), dim3(64), 0, ctx->stream, d_sw.p, nsweeps, d_tr_in,
                        d_st.p);
+#ifdef GPSCAL_STATS
+    hipLaunchKernelGGL(loam_stat_slot_kernel, dim3(1), dim3(1), 0, ctx->stream, 2);
+#endif
     for (int it = 0; it < 10; ++it) {  // LM:752; converged sweeps return at once
         hipLaunchKernelGGL(lm_point_kernel, dim3(tiles_max, nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_cstack,
                            d_sstack, d_cmap, d_smap, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p,
