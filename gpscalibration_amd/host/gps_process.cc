@@ -67,7 +67,9 @@ struct Fields {
 double ddmm_to_deg(const char *tok)
 {
     const double v = atof(tok);
-    const int d = (int)(v / 100);  // truncation as in gps_process.cc:191,205
+    // truncation as in gps_process.cc:191,205 (an int cast there); in double here, so that a damaged field
+    // (121238894999...9.25) is a wrong coordinate and not an overflow -- identical for every value an int holds
+    const double d = std::trunc(v / 100);
     return d + (v - d * 100) / 60.0;
 }
 

@@ -252,3 +252,147 @@ def test_rosbag_reader_view_semantics_and_malformed_files(tmp_path):
                            corrupt=bad)
         with pytest.raises(RuntimeError):
             pipeline.read_bag(path, "velodyne_points")
+
+
+def test_rosbag_reader_under_address_and_ub_sanitizers(tmp_path):
+    """The bag reader parses files it did not write: it is built here with -fsanitize=address,undefined (CPU build
+    only; the GPU pool has no sanitizer) and fed a valid bag, the three declared-layout corruptions, truncations at
+    every record boundary region and a few hundred random byte mutations.  Every file must end in "OK" or in the
+    reader's own "ERR ..." -- never in a sanitizer report, a crash or a hang."""
+    import shutil
+    import subprocess
+    from gpscalibration_amd import synth
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    host = os.path.join(ROOT, "gpscalibration_amd", "host")
+    exe = str(tmp_path / "reader_asan")
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-I", host, os.path.join(ROOT, "tests", "sanitize", "reader_main.cc"),
+           os.path.join(host, "rosbag_reader.cc"), "-ldl", "-o", exe]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0 and "sanitize" in r.stdout and "cannot find" in r.stdout:
+        pytest.skip("sanitizer runtime not installed: " + r.stdout[-200:])
+    assert r.returncode == 0, r.stdout[-2000:]
+    rng = np.random.default_rng(11)
+    sweeps = [rng.normal(0, 15, (n, 3)).astype(np.float32) for n in (300, 1, 700, 64, 0, 512)]
+    stamps = 1494650700.0 + 0.1 * np.arange(len(sweeps))
+    files = []
+    for comp in ("none", "bz2"):
+        good = str(tmp_path / ("good_%s.bag" % comp))
+        synth.write_rosbag(good, sweeps, stamps, chunk_msgs=2, compression=comp, publishers=2)
+        files.append(good)
+        blob = open(good, "rb").read()
+        # truncations: every 97 bytes through the header region, then a spread over the rest
+        cuts = list(range(0, min(len(blob), 4200), 97)) + [int(x) for x in np.linspace(4200, len(blob) - 1, 40)]
+        for c in cuts:
+            path = str(tmp_path / ("cut_%s_%d.bag" % (comp, c)))
+            open(path, "wb").write(blob[:c])
+            files.append(path)
+        # random mutations: a few bytes overwritten (lengths, offsets, field names and payload alike)
+        for k in range(150):
+            b = bytearray(blob)
+            for _ in range(int(rng.integers(1, 6))):
+                pos = int(rng.integers(0, len(b)))
+                b[pos] = int(rng.integers(0, 256)) if rng.random() < 0.7 else (0xff if rng.random() < 0.5 else 0)
+            path = str(tmp_path / ("mut_%s_%d.bag" % (comp, k)))
+            open(path, "wb").write(bytes(b))
+            files.append(path)
+    for bad in ("field_offset", "huge_width", "chunk_size"):
+        path = str(tmp_path / ("bad_%s.bag" % bad))
+        synth.write_rosbag(path, sweeps[:4], stamps[:4], chunk_msgs=3, compression="bz2" if bad == "chunk_size" else "none",
+                           corrupt=bad)
+        files.append(path)
+    env = dict(os.environ, ASAN_OPTIONS="exitcode=99:detect_leaks=1:allocator_may_return_null=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    nok = nerr = 0
+    for a in range(0, len(files), 64):
+        batch = files[a:a + 64]
+        r = subprocess.run([exe, "velodyne_points"] + batch, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           env=env, timeout=300)
+        assert r.returncode == 0, "sanitizer report or crash (rc %d) on one of %s:\n%s" % (r.returncode, batch[:3], r.stderr[-3000:])
+        lines = r.stdout.strip().splitlines()
+        assert len(lines) == len(batch)
+        assert all(ln.startswith(("OK ", "ERR ")) for ln in lines)
+        nok += sum(ln.startswith("OK ") for ln in lines)
+        nerr += sum(ln.startswith("ERR ") for ln in lines)
+    assert nok >= 2 and nerr >= 50, (nok, nerr)  # the good bags read, the truncated ones are refused
+
+
+def test_gps_log_parser_under_address_and_ub_sanitizers(tmp_path):
+    """The NMEA ingest (GPSPro::parseGPRMC / gpsProcess, host/gps_process.cc) under -fsanitize=address,undefined on the
+    reference's own GPRMC log (tests/golden/original_gps_data.txt, a data fixture) and on damaged copies of it: lines
+    cut short, fields dropped or emptied, digits replaced by junk, absurd numbers, binary noise, no trailing newline.
+    Every log must parse to "OK" / "ERR" -- no sanitizer report, no crash."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    host = os.path.join(ROOT, "gpscalibration_amd", "host")
+    lib = os.path.join(ROOT, "gpscalibration_amd")
+    if not os.path.exists(os.path.join(lib, "libgpscal_host.so")):
+        pytest.skip("libgpscal_host.so not built")
+    exe = str(tmp_path / "gpslog_asan")
+    # gps_process.cc is compiled with the sanitizers; the C-ABI symbols it references (never called here) come from
+    # the uninstrumented libraries
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-I", host, "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "sanitize", "gpslog_main.cc"), os.path.join(host, "gps_process.cc"),
+           "-L", lib, "-lgpscal_host", "-lgpscal_hip", "-Wl,-rpath," + lib, "-ldl", "-o", exe]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0 and "sanitize" in r.stdout and "cannot find" in r.stdout:
+        pytest.skip("sanitizer runtime not installed: " + r.stdout[-200:])
+    assert r.returncode == 0, r.stdout[-2000:]
+    text = open(os.path.join(ROOT, "tests", "golden", "original_gps_data.txt"), "rb").read()
+    lines = text.split(b"\n")
+    rng = np.random.default_rng(5)
+    files = []
+
+    def emit(name, blob):
+        path = str(tmp_path / name)
+        open(path, "wb").write(blob)
+        files.append(path)
+
+    emit("whole.txt", text)
+    emit("empty.txt", b"")
+    emit("no_newline.txt", text.rstrip(b"\n")[:5000])
+    emit("noise.bin", bytes(rng.integers(0, 256, 20000, dtype=np.uint8)))
+    emit("commas.txt", b",,,,,,,,,,,,\n" * 50 + b"$GPRMC" + b"," * 40 + b"\n")
+    emit("huge_numbers.txt", b"\n".join(ln.replace(b".", b"9" * 60 + b".", 2) for ln in lines[:200]))
+    for k in range(120):
+        out = []
+        for ln in lines[:400]:
+            u = rng.random()
+            if u < 0.05:
+                ln = ln[:int(rng.integers(0, len(ln) + 1))]
+            elif u < 0.10:
+                parts = ln.split(b",")
+                if len(parts) > 2:
+                    del parts[int(rng.integers(0, len(parts)))]
+                ln = b",".join(parts)
+            elif u < 0.15:
+                parts = ln.split(b",")
+                if parts:
+                    parts[int(rng.integers(0, len(parts)))] = b""
+                ln = b",".join(parts)
+            elif u < 0.20 and len(ln) > 0:
+                b = bytearray(ln)
+                for _ in range(int(rng.integers(1, 5))):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+                ln = bytes(b)
+            elif u < 0.22:
+                ln = ln * int(rng.integers(2, 40))
+            out.append(ln)
+        emit("mut_%d.txt" % k, b"\n".join(out))
+    env = dict(os.environ, ASAN_OPTIONS="exitcode=99:detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    nok = 0
+    for a in range(0, len(files), 32):
+        batch = files[a:a + 32]
+        r = subprocess.run([exe] + batch, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+        assert r.returncode == 0, "sanitizer report or crash (rc %d):\n%s" % (r.returncode, r.stderr[-3000:])
+        out = [ln for ln in r.stdout.strip().splitlines() if ln.startswith(("OK ", "ERR "))]
+        assert len(out) == len(batch), r.stdout[-1000:]
+        nok += sum(ln.startswith("OK ") for ln in out)
+    assert nok >= 1
+
