@@ -38,8 +38,13 @@
  *     OUTPUT is ready only after gpscal_sync(ctx), or for work enqueued on a
  *     stream that was passed to gpscal_make_stream_wait(ctx, consumer_stream)
  *     after the call, or on the stream gpscal_stream(ctx) returns;
- *   - a context is bound to one GPU and one host thread at a time (the
- *     reference's nodes are single-threaded: LD:128-132, SD:223-231);
+ *   - a context is bound to one GPU and one CALLING thread at a time (the
+ *     reference's nodes are single-threaded: LD:128-132, SD:223-231).  Two
+ *     entry points run the LOAM nodes concurrently, as the reference's ROS
+ *     nodes do: gpscal_loam_run_batched and gpscal_input_data_run start one
+ *     worker thread and one extra stream for the duration of the call and
+ *     join / destroy them before they return (GPSCAL_LOAM_PIPELINE=0 keeps
+ *     everything on the calling thread; the results are identical);
  *   - there is NO CPU fallback: without a usable gfx950 device gpscal_create
  *     fails with GPSCAL_ENODEV and nothing else can be called.
  *
@@ -318,7 +323,9 @@ int gpscal_voxel_grid_batched(gpscal_ctx *ctx, int nclouds, const float *pts_xyz
  * transformMaintenance's integration and height compensation (TM:113-157, 178-337) that
  * produces the /true_odometry_to_init samples input_data collects into the SLAM track
  * (ID:266-444).  Schedule: each node finishes a sweep before the next one arrives (the
- * reference's bag playback rate guarantees this); no IMU.
+ * reference's bag playback rate guarantees this); no IMU.  laserOdometry runs up to three sweeps
+ * ahead of transformMaintenance + laserMapping (own thread and stream): nothing flows back from
+ * mapping to odometry, so every node sees its inputs in that schedule's order.
  * xyz = packed float[3] raw points, sweep_off = nsweeps+1 point offsets over ALL sweeps,
  * seg_sweep_off = nseg+1 sweep-index offsets (seg_sweep_off[0] = 0), stamps = one per sweep.
  * Outputs, one row per sweep (optional unless noted): lo_sum = laserOdometry's transformSum,
@@ -341,7 +348,9 @@ int gpscal_loam_run_batched(gpscal_ctx *ctx, int nseg, const float *xyz,
  * slam - overlap, laserOdometry reset through /control_command at every cut, ID:283-286,342-346),
  * including the final rule that replays from the start of the previous segment when the rest is
  * shorter than a third of the segment length (ID:366-414).  All 2 x nbag streams advance in lock
- * step on the device.  Inputs as gpscal_loam_run_batched, with bag_sweep_off = nbag+1 sweep-index
+ * step on the device; within a step, the mapping cycle overlaps the NEXT step's laserOdometry (a cut
+ * decision needs transformMaintenance's sample of its own step only, which depends on the previous
+ * mapping cycle).  Inputs as gpscal_loam_run_batched, with bag_sweep_off = nbag+1 sweep-index
  * offsets.  Outputs (host arrays): per track its flag (0 long / 1 short, the IMTrack.track_flag of
  * ID:347), bag, first / last replayed message (1-based within the bag), and rows
  * track_off[k]..track_off[k+1] of track_xyzt = the IMLocalXYZT samples {x, y, z, t} (ID:80-88).
