@@ -261,6 +261,10 @@ __device__ __forceinline__ void scan_short(BT &B, bool act, const float4 *__rest
     }
 #endif
     if (!act) return;
+#ifdef GPSCAL_SCAN_DIAG  // ablation (wrong results): 1 = no candidate is read, 2 = only the first of a run
+    if (GPSCAL_SCAN_DIAG == 1) return;
+    if (GPSCAL_SCAN_DIAG == 2) e = min(e, s + 1u);
+#endif
     unsigned j = s;
     // full groups of four: no clamps, no per-candidate guards
     for (; j + 4 <= e; j += 4) {
@@ -439,6 +443,104 @@ __device__ __forceinline__ void block3_level(const GridDesc &G, const CellGeo &C
     }
 }
 
+// The same level search for kernels that run at under one wave per SIMD (the LOAM searches), where a search is a
+// CHAIN of dependent round trips and the chain's length is what counts: a lane needs ~3 of the 9 rows and which
+// ones differs from lane to lane, so visiting the rows one after the other costs the wave the sum over rows of the
+// longest run in each (laserOdometry: 119 groups of four per wave against 29 per lane).  Here the own row is scanned
+// first (it tightens the bound), then the cell boundaries of the other rows are fetched FLAT_BATCH rows at a time,
+// every lane lists the candidate runs of its rows in a wave-private LDS slab (8 x 64 uint2 = 4 KiB per wave) and
+// walks its own list in groups of four: the wave pays the longest LIST.  Candidates may be evaluated twice (a
+// clamped group): records order by (d2, index), which makes that idempotent.  (Measured on icp_step_kernel, which is
+// bound by the rate of gathers and not by their latency: no gain, commit 41733d4.)
+constexpr int FLAT_BATCH = 4;
+template <class BT>
+__device__ __forceinline__ void block3_level_flat(const GridDesc &G, const CellGeo &C,
+                                                  const float4 *__restrict__ sorted,
+                                                  const unsigned *__restrict__ cell_start, bool act, float px,
+                                                  float py, float pz, BT &B, uint2 *__restrict__ slab)
+{
+    const float mg = G.margin;
+    const float bxl = fmaxf(C.fx0 - mg, 0.f), bxr = fmaxf(C.fx1 - mg, 0.f);
+    const float bxl2 = bxl * bxl, bxr2 = bxr * bxr;
+    const bool has_l = C.cx > 0, has_r = C.cx + 1 < G.nx;
+    const float by2[3] = {0.f, fmaxf(C.fy0 - mg, 0.f) * fmaxf(C.fy0 - mg, 0.f),
+                          fmaxf(C.fy1 - mg, 0.f) * fmaxf(C.fy1 - mg, 0.f)};
+    const float bz2[3] = {0.f, fmaxf(C.fz0 - mg, 0.f) * fmaxf(C.fz0 - mg, 0.f),
+                          fmaxf(C.fz1 - mg, 0.f) * fmaxf(C.fz1 - mg, 0.f)};
+    const bool yok[3] = {true, C.cy > 0, C.cy + 1 < G.ny};
+    const bool zok[3] = {true, C.cz > 0, C.cz + 1 < G.nz};
+    const int lane = threadIdx.x & 63;
+    const long long own = G.cell_base + ((long long)C.cz * G.ny + C.cy) * G.nx + C.cx;
+    const long long dyo = G.nx, dzo = (long long)G.ny * G.nx;
+    {  // the own row
+        CellQuad q = {0u, 0u, 0u, 0u};
+        if (act) q = *reinterpret_cast<const CellQuad *>(cell_start + own - 1);
+        const unsigned c0 = has_l ? q.a : q.b, c1 = q.b, c2 = q.c, c3 = has_r ? q.d : q.c;
+        const bool pl0 = act && c0 < c1 && bxl2 * 0.99999f <= B.worst();
+        const bool pr0 = act && c2 < c3 && bxr2 * 0.99999f <= B.worst();
+        STAT_WAVE(5, 1);
+        scan_short(B, act, sorted, pl0 ? c0 : c1, pr0 ? c3 : c2, px, py, pz);
+    }
+    unsigned cnt = 0;
+#pragma unroll
+    for (int half = 0; half < 8 / FLAT_BATCH; ++half) {
+        CellQuad q[FLAT_BATCH];
+        bool p[FLAT_BATCH];
+#pragma unroll
+        for (int t = 0; t < FLAT_BATCH; ++t) {
+            const int r = 1 + half * FLAT_BATCH + t, kz = r / 3, ky = r - 3 * kz;
+            p[t] = act && yok[ky] && zok[kz] && (by2[ky] + bz2[kz]) * 0.99999f <= B.worst();
+            q[t] = CellQuad{0u, 0u, 0u, 0u};
+            if (p[t]) {
+                const long long row = own + (ky == 0 ? 0 : (ky == 1 ? -dyo : dyo)) + (kz == 0 ? 0 : (kz == 1 ? -dzo : dzo));
+                q[t] = *reinterpret_cast<const CellQuad *>(cell_start + row - 1);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < FLAT_BATCH; ++t) {
+            const int r = 1 + half * FLAT_BATCH + t, kz = r / 3, ky = r - 3 * kz;
+            const float rb2 = by2[ky] + bz2[kz];
+            const unsigned c0 = has_l ? q[t].a : q[t].b, c1 = q[t].b, c2 = q[t].c, c3 = has_r ? q[t].d : q[t].c;
+            const bool pl0 = p[t] && c0 < c1 && (rb2 + bxl2) * 0.99999f <= B.worst();
+            const bool pr0 = p[t] && c2 < c3 && (rb2 + bxr2) * 0.99999f <= B.worst();
+            const unsigned s = pl0 ? c0 : c1, e = pr0 ? c3 : c2;
+            if (p[t] && e > s) {
+                slab[cnt * 64 + lane] = make_uint2(s, e);
+                ++cnt;
+            }
+        }
+    }
+    // every lane walks its own list; the next entry is fetched while the current run is scanned
+    unsigned j = 0u, e = 0u, k = 2u;
+    uint2 nx = make_uint2(0u, 0u);
+    if (cnt > 0u) {
+        const uint2 r0 = slab[lane];
+        j = r0.x;
+        e = r0.y;
+    }
+    if (cnt > 1u) nx = slab[64 + lane];
+    while (__ballot(j < e) != 0ull) {
+        STAT_WAVE(18, 1);
+        if (j < e) {
+            const unsigned last = e - 1u;
+            const unsigned j1 = min(j + 1u, last), j2 = min(j + 2u, last), j3 = min(j + 3u, last);
+            const float4 c0 = sorted[j], c1 = sorted[j1], c2 = sorted[j2], c3 = sorted[j3];
+            B.consider(sqdist(px, py, pz, c0.x, c0.y, c0.z), c0, j);
+            B.consider(sqdist(px, py, pz, c1.x, c1.y, c1.z), c1, j1);
+            B.consider(sqdist(px, py, pz, c2.x, c2.y, c2.z), c2, j2);
+            B.consider(sqdist(px, py, pz, c3.x, c3.y, c3.z), c3, j3);
+            j += 4u;
+            if (j >= e) {
+                j = nx.x;
+                e = nx.y;
+                nx = make_uint2(0u, 0u);
+                if (k < cnt) nx = slab[k * 64 + lane];
+                ++k;
+            }
+        }
+    }
+}
+
 // One level of the ball search: every cell of a (2R+1)^3 block that the ball around the query
 // with the current k-th best distance as radius still reaches.  Slabs (fixed z) and rows (fixed
 // y,z) are visited nearest first and dropped when their face is out of reach; of a row only the
@@ -499,7 +601,7 @@ __device__ __forceinline__ void ball_level(const GridDesc &G, const CellGeo &C, 
 template <class BT, bool ALLOW_BALL = false>
 __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__restrict__ sorted,
                                           const unsigned *__restrict__ cell_start, bool act, float px, float py,
-                                          float pz, BT &B, int ball_r = 0)
+                                          float pz, BT &B, int ball_r = 0, uint2 *__restrict__ slab = nullptr)
 {
     if (!act) px = py = pz = 0.f;
     const bool ballmode = ALLOW_BALL && BT::BALL && ball_r > 0;
@@ -550,7 +652,10 @@ __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__res
             STAT_WAVE(4, __popcll(__ballot(a)));
             STAT_WAVE(11 + min(l, 4), __popcll(__ballot(a)));
             if (!ALLOW_BALL || __ballot(a && far) == 0ull) {
-                block3_level(G, C, sorted, cell_start, a, px, py, pz, B);
+                if (!BT::COOP && slab)  // latency-bound callers hand in a wave-private slab (block3_level_flat)
+                    block3_level_flat(G, C, sorted, cell_start, a, px, py, pz, B, slab);
+                else
+                    block3_level(G, C, sorted, cell_start, a, px, py, pz, B);
             } else {
                 ball_level(G, C, sorted, cell_start, a, px, py, pz, B, ball_r);
             }
@@ -575,7 +680,7 @@ __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__res
 template <class BT>
 __device__ __forceinline__ void knn_query_lanes(const PairDesc *__restrict__ Pl, const float4 *__restrict__ sorted,
                                                 const unsigned *__restrict__ cell_start, bool act, float px, float py,
-                                                float pz, BT &B)
+                                                float pz, BT &B, uint2 *__restrict__ slab = nullptr)
 {
     if (!act) px = py = pz = 0.f;
     const int nl = Pl->nlevels;
@@ -602,7 +707,10 @@ __device__ __forceinline__ void knn_query_lanes(const PairDesc *__restrict__ Pl,
         const GridDesc G = Pl->lv[min(l, nl - 1)];
         CellGeo C;
         C.set(G, px, py, pz);
-        block3_level(G, C, sorted, cell_start, a, px, py, pz, B);
+        if (slab)
+            block3_level_flat(G, C, sorted, cell_start, a, px, py, pz, B, slab);
+        else
+            block3_level(G, C, sorted, cell_start, a, px, py, pz, B);
         if (a && (B.worst() <= C.settled_r2(G) || l == nl - 1)) todo = false;
     }
 }

@@ -34,6 +34,7 @@ struct GridSource {
     const long long *off;
     int npairs;
     GridSet *gs;
+    float cell = 0.f;  // this set's level-0 cell size (0: the call's); < 0: -cell points per footprint cell
 };
 int build_grids_multi(gpscal_ctx *ctx, int nsrc, const GridSource *src, int stride, float cell, int max_levels);
 // Neighbour lists + certified radii (ICP only).

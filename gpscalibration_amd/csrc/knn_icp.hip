@@ -692,10 +692,10 @@ static void plan_levels(const float mn[3], const float mx[3], int m, float cell,
     float h0 = cell;
     if (!(h0 > 0.f)) {
         // lidar clouds are surfaces: aim at ~3 points per occupied cell of the
-        // footprint (the two largest extents)
+        // footprint (the two largest extents); cell < 0: -cell points per cell instead of 3
         float e0 = ext[0], e1 = ext[1], e2 = ext[2];
         float area = std::max(e0 * e1, std::max(e0 * e2, e1 * e2));
-        h0 = std::sqrt(3.0f * area / (float)std::max(m, 1));
+        h0 = std::sqrt((cell < 0.f ? -cell : 3.0f) * area / (float)std::max(m, 1));
     }
     if (!(h0 > 0.f) || !std::isfinite(h0)) h0 = 1.0f;
     h0 = std::max(h0, emax / 1024.0f);
@@ -819,7 +819,7 @@ int build_grids_multi(gpscal_ctx *ctx, int nsrc, const GridSource *src, int stri
                 mx[a] = ord2f(hbk[b * 6 + 3 + a]);
                 if (!(mn[a] <= mx[a])) mn[a] = mx[a] = 0.f;  // empty / all-NaN cloud
             }
-            plan_levels(mn, mx, P.m, cell, max_levels, P);
+            plan_levels(mn, mx, P.m, src[k].cell != 0.f ? src[k].cell : cell, max_levels, P);
             // levels whose cells (counted from the top) fit the LDS histogram are aggregated there
             {
                 long long acc = 0;
@@ -878,7 +878,7 @@ int build_grids_multi(gpscal_ctx *ctx, int nsrc, const GridSource *src, int stri
 int build_grids(gpscal_ctx *ctx, const void *xyz, int stride, const long long *off, int npairs, float cell,
                 int max_levels, GridSet &gs)
 {
-    const GridSource one = {xyz, off, npairs, &gs};
+    const GridSource one = {xyz, off, npairs, &gs, 0.f};
     return build_grids_multi(ctx, 1, &one, stride, cell, max_levels);
 }
 

@@ -26,6 +26,9 @@
 
 namespace gpscal {
 
+#ifndef GPSCAL_LOAM_FLAT
+#define GPSCAL_LOAM_FLAT 1  // the searches of lo_search_kernel / lm_point_kernel walk per-lane run lists (block3_level_flat)
+#endif
 #ifndef GPSCAL_LO_DIAG
 #define GPSCAL_LO_DIAG 0  // ablations of lo_search_kernel (wrong results): 1 = no ring searches, 2 = no nearest search
 #endif
@@ -296,7 +299,8 @@ __device__ __noinline__ bool solve_update(const double (&tot)[LSUMS], bool first
 // neighbour either way).
 __device__ __forceinline__ void lo_nearest(const PairDesc &P, const float4 *__restrict__ sorted,
                                            const unsigned *__restrict__ cell_start, bool act, float4 p, int &idx,
-                                           float &sqd, const float4 *__restrict__ cloud = nullptr, int seed = -1)
+                                           float &sqd, const float4 *__restrict__ cloud = nullptr, int seed = -1,
+                                           uint2 *__restrict__ slab = nullptr)
 {
     Best<1> B;
     B.init_radius(25.f);  // LO:607,758: a nearest point at 5 m or more is no correspondence
@@ -304,7 +308,7 @@ __device__ __forceinline__ void lo_nearest(const PairDesc &P, const float4 *__re
         const float4 c = cloud[seed];
         B.consider(sqdist(p.x, p.y, p.z, c.x, c.y, c.z), make_float4(c.x, c.y, c.z, __int_as_float(seed)), 0u);
     }
-    if (!(GPSCAL_LO_DIAG & 2)) knn_query(P, sorted, cell_start, act, p.x, p.y, p.z, B);
+    if (!(GPSCAL_LO_DIAG & 2)) knn_query(P, sorted, cell_start, act, p.x, p.y, p.z, B, 0, slab);
     idx = B.i[0] == 0x7fffffff ? -1 : B.i[0];
     sqd = B.d[0];
 }
@@ -525,6 +529,12 @@ __global__ __launch_bounds__(PT_BLOCK) void lm_point_kernel(
     const int ct = (D.nc + PT_BLOCK - 1) / PT_BLOCK, stl = (D.ns + PT_BLOCK - 1) / PT_BLOCK;
     const int tile = blockIdx.x;
     if (tile >= ct + stl) return;
+#if GPSCAL_LOAM_FLAT
+    __shared__ uint2 s_slab[PT_BLOCK / 64][8 * 64];  // per wave: the run lists of block3_level_flat
+    uint2 *slab = &s_slab[threadIdx.x >> 6][0];
+#else
+    uint2 *slab = nullptr;
+#endif
     double sum[LSUMS];
 #pragma unroll
     for (int k = 0; k < LSUMS; ++k) sum[k] = 0.0;
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(PT_BLOCK) void lm_point_kernel(
                 B.consider(sqdist(ps.x, ps.y, ps.z, c.x, c.y, c.z), make_float4(c.x, c.y, c.z, __int_as_float(pj)), 0u);
             }
         }
-        knn_query(cpairs[b], csorted, ccells, act, ps.x, ps.y, ps.z, B);
+        knn_query(cpairs[b], csorted, ccells, act, ps.x, ps.y, ps.z, B, 0, slab);
         if (act) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) pv[j] = B.i[4] == 0x7fffffff ? -1 : B.i[j];
@@ -625,7 +635,7 @@ __global__ __launch_bounds__(PT_BLOCK) void lm_point_kernel(
                 B.consider(sqdist(ps.x, ps.y, ps.z, c.x, c.y, c.z), make_float4(c.x, c.y, c.z, __int_as_float(pj)), 0u);
             }
         }
-        knn_query(spairs[b], ssorted, scells, act, ps.x, ps.y, ps.z, B);
+        knn_query(spairs[b], ssorted, scells, act, ps.x, ps.y, ps.z, B, 0, slab);
         if (act) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) pv[j] = B.i[4] == 0x7fffffff ? -1 : B.i[j];
@@ -783,14 +793,14 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_init_kernel(const SweepDesc *__re
 // points from 0, hence R.base.
 __device__ __forceinline__ void ring_search(const PairDesc *__restrict__ rp, const float4 *__restrict__ rsorted,
                                             const unsigned *__restrict__ rcells, const int *rs, bool has, int want,
-                                            float4 ps, BestRing &R)
+                                            float4 ps, BestRing &R, uint2 *__restrict__ slab = nullptr)
 {
     if (GPSCAL_LO_DIAG & 1) return;
     // every lane searches the grid of the ring it wants, all of them in one pass (knn_query_lanes)
     const bool sel = has && want >= 0 && want <= 15;
     const int r = sel ? want : 0;
     if (sel) R.base = rs[r];
-    knn_query_lanes(rp + r, rsorted, rcells, sel, ps.x, ps.y, ps.z, R);
+    knn_query_lanes(rp + r, rsorted, rcells, sel, ps.x, ps.y, ps.z, R, slab);
 }
 
 // the previous round's answer as the first candidate of a ring search (it still has to pass the record's
@@ -821,6 +831,12 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     if (tile >= ct + stl) return;
     __shared__ float tr[6];
     __shared__ int s_rs_c[18], s_rs_s[18];
+#if GPSCAL_LOAM_FLAT
+    __shared__ uint2 s_slab[PT_BLOCK / 64][8 * 64];  // per wave: the run lists of block3_level_flat
+    uint2 *slab = &s_slab[threadIdx.x >> 6][0];
+#else
+    uint2 *slab = nullptr;
+#endif
     if (threadIdx.x < 6) tr[threadIdx.x] = st[b].tr[threadIdx.x];
     if (threadIdx.x < 18) {
         s_rs_c[threadIdx.x] = st[b].rs_c[threadIdx.x];
@@ -830,8 +846,7 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     const bool mono = st[b].mono != 0;
     const bool ring_grids = rcpairs != nullptr && st[b].ring_ok != 0;
     STAT_WAVE(2, 1);  // waves of lo_search_kernel
-    STAT_WAVE(21, mono ? 1 : 0);
-    STAT_WAVE(22, ring_grids ? 1 : 0);
+    STAT_WAVE(22, ring_grids && mono ? 1 : 0);
     const PairDesc &CP = cpairs[b];
     const PairDesc &SP = spairs[b];
     const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off, *cl = clast + D.clast_off,
@@ -849,7 +864,15 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
         int idx;
         float sqd;
         const int prev1 = act ? ci1[i] : -1, prev2 = act ? ci2[i] : -1;  // -1 in a sweep's first round (lo_init_kernel)
-        lo_nearest(CP, csorted, ccells, act, ps, idx, sqd, cl, prev1);
+#ifdef GPSCAL_STATS
+        const unsigned long long tk0 = wall_clock64();
+#endif
+        lo_nearest(CP, csorted, ccells, act, ps, idx, sqd, cl, prev1, slab);
+#ifdef GPSCAL_STATS
+        const unsigned long long tk1 = wall_clock64();
+        STAT_WAVE(19, tk1 - tk0);  // corner tiles: ticks (10 ns) in the nearest search
+        STAT_WAVE(9, 1);
+#endif
         int closest = -1, min2 = -1;
         const bool has = act && idx >= 0 && sqd < 25;
         if (has) closest = idx;
@@ -869,10 +892,10 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
             ring_seed(R, has, cl, prev2, ps);
             if (ring_grids) {
                 const int scan = has ? (int)cl[closest].w : -9;
-                ring_search(rcpairs + 16 * b, rcsorted, rccells, s_rs_c, has && a1 > a0, scan - 1, ps, R);
-                ring_search(rcpairs + 16 * b, rcsorted, rccells, s_rs_c, has && b1 > b0, scan + 1, ps, R);
+                ring_search(rcpairs + 16 * b, rcsorted, rccells, s_rs_c, has && a1 > a0, scan - 1, ps, R, slab);
+                ring_search(rcpairs + 16 * b, rcsorted, rccells, s_rs_c, has && b1 > b0, scan + 1, ps, R, slab);
             } else {
-                knn_query(CP, csorted, ccells, has, ps.x, ps.y, ps.z, R);
+                knn_query(CP, csorted, ccells, has, ps.x, ps.y, ps.z, R, 0, slab);
             }
             if (has) min2 = R.i;
         } else if (has) {
@@ -921,6 +944,9 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
                 }
             }
         }
+#ifdef GPSCAL_STATS
+        STAT_WAVE(20, wall_clock64() - tk1);  // ... and in the ring searches
+#endif
         if (act) {
             ci1[i] = closest;
             ci2[i] = min2;
@@ -934,7 +960,15 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
         int idx;
         float sqd;
         const int prev1 = act ? si1[i] : -1, prev2 = act ? si2[i] : -1, prev3 = act ? si3[i] : -1;
-        lo_nearest(SP, ssorted, scells, act, ps, idx, sqd, sl, prev1);
+#ifdef GPSCAL_STATS
+        const unsigned long long tk0 = wall_clock64();
+#endif
+        lo_nearest(SP, ssorted, scells, act, ps, idx, sqd, sl, prev1, slab);
+#ifdef GPSCAL_STATS
+        const unsigned long long tk1 = wall_clock64();
+        STAT_WAVE(21, tk1 - tk0);  // surf tiles: nearest search
+        STAT_WAVE(10, 1);
+#endif
         int closest = -1, min2 = -1, min3 = -1;
         const bool has = act && idx >= 0 && sqd < 25;
         if (has) closest = idx;
@@ -960,12 +994,12 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
             ring_seed(R3, has, sl, prev3, ps);
             if (ring_grids) {
                 const int scan = has ? (int)sl[closest].w : -9;
-                ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && (a1 > a0 || b1 > b0), scan, ps, R2);
-                ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && c1 > c0, scan - 1, ps, R3);
-                ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && e1 > e0, scan + 1, ps, R3);
+                ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && (a1 > a0 || b1 > b0), scan, ps, R2, slab);
+                ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && c1 > c0, scan - 1, ps, R3, slab);
+                ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && e1 > e0, scan + 1, ps, R3, slab);
             } else {
-                knn_query(SP, ssorted, scells, has, ps.x, ps.y, ps.z, R2);
-                knn_query(SP, ssorted, scells, has, ps.x, ps.y, ps.z, R3);
+                knn_query(SP, ssorted, scells, has, ps.x, ps.y, ps.z, R2, 0, slab);
+                knn_query(SP, ssorted, scells, has, ps.x, ps.y, ps.z, R3, 0, slab);
             }
             if (has) {
                 min2 = R2.i;
@@ -1017,6 +1051,9 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
                 }
             }
         }
+#ifdef GPSCAL_STATS
+        STAT_WAVE(23, wall_clock64() - tk1);  // surf tiles: ring searches
+#endif
         if (act) {
             si1[i] = closest;
             si2[i] = min2;
@@ -1260,10 +1297,12 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
     }
     {
         // all four index sets in one call: one host wait (their bounding boxes) instead of four
-        GridSource srcs[4] = {{d_clast, coff, nsweeps, &cg},
-                              {d_slast, soff, nsweeps, &sg},
-                              {d_clast, roc.data(), nsweeps * 16, &rcg},
-                              {d_slast, ros.data(), nsweeps * 16, &rsg}};
+        // (the per-ring grids keep the even-surface cell size although a ring is a curve: its level 0 then
+        // covers laserOdometry's 5 m radius in one pass; 10x / 100x / 1000x finer cells were measured 2 % / 10 % / 64 % slower)
+        GridSource srcs[4] = {{d_clast, coff, nsweeps, &cg, 0.f},
+                              {d_slast, soff, nsweeps, &sg, 0.f},
+                              {d_clast, roc.data(), nsweeps * 16, &rcg, 0.f},
+                              {d_slast, ros.data(), nsweeps * 16, &rsg, 0.f}};
         int rc = build_grids_multi(ctx, ring_grids ? 4 : 2, srcs, 16, 0.f, MAX_LEVELS);
         if (rc) return rc;
     }
@@ -1382,7 +1421,7 @@ int loam_mapping_device(gpscal_ctx *ctx, int nsweeps, const MapDesc *descs, cons
     GridSet cg, sg;
     cg.pooled = sg.pooled = pool_grids();
     {
-        GridSource srcs[2] = {{d_cmap, cmoff, nsweeps, &cg}, {d_smap, smoff, nsweeps, &sg}};
+        GridSource srcs[2] = {{d_cmap, cmoff, nsweeps, &cg, 0.f}, {d_smap, smoff, nsweeps, &sg, 0.f}};
         int rc = build_grids_multi(ctx, 2, srcs, 16, 0.f, MAX_LEVELS);
         if (rc) return rc;
     }
