@@ -7,7 +7,7 @@ import glob
 import json
 import sys
 
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+f = sorted(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*kernel_trace.csv"))[-1]
 bench = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
 rows = list(csv.DictReader(open(f)))
 d = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
