@@ -814,6 +814,13 @@ __device__ __forceinline__ void ring_seed(BestRing &R, bool has, const float4 *_
     }
 }
 
+// A tile is 64 features and a workgroup its four waves: wave 0 finds every feature's nearest point of the last
+// cloud; the adjacent-ring searches need only that result and are independent of each other, so after a barrier
+// waves 1..3 run one of them each (corner: rings scan-1 | scan+1 -> min2; surf: own ring -> min2, rings scan-1 |
+// scan+1 -> min3) and wave 0 joins the partial records in the record's own order (squared distance, then the order
+// the sequential walk would meet the candidates).  One after the other in one lane they were a chain of ~160 us at
+// under one wave per SIMD; side by side the launch is as long as the nearest search plus ONE ring search.
+constexpr int LO_TILE = 64;
 __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     const SweepDesc *__restrict__ sweeps, const float4 *__restrict__ sharp, const float4 *__restrict__ flat,
     const float4 *__restrict__ clast, const float4 *__restrict__ slast, const PairDesc *__restrict__ cpairs,
@@ -823,14 +830,19 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     const unsigned *__restrict__ rccells, const PairDesc *__restrict__ rspairs, const float4 *__restrict__ rssorted,
     const unsigned *__restrict__ rscells)
 {
+    static_assert(PT_BLOCK == 4 * LO_TILE, "four waves per tile of 64 features");
     const int b = blockIdx.y;
     if (st[b].done) return;
     const SweepDesc D = sweeps[b];
-    const int ct = (D.nc + PT_BLOCK - 1) / PT_BLOCK, stl = (D.ns + PT_BLOCK - 1) / PT_BLOCK;
+    const int ct = (D.nc + LO_TILE - 1) / LO_TILE, stl = (D.ns + LO_TILE - 1) / LO_TILE;
     const int tile = blockIdx.x;
     if (tile >= ct + stl) return;
     __shared__ float tr[6];
     __shared__ int s_rs_c[18], s_rs_s[18];
+    __shared__ int s_closest[LO_TILE];
+    __shared__ float s_rd[4][LO_TILE];
+    __shared__ unsigned s_ro[4][LO_TILE];
+    __shared__ int s_ri[4][LO_TILE];
 #if GPSCAL_LOAM_FLAT
     __shared__ uint2 s_slab[PT_BLOCK / 64][8 * 64];  // per wave: the run lists of block3_level_flat
     uint2 *slab = &s_slab[threadIdx.x >> 6][0];
@@ -845,8 +857,8 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     __syncthreads();
     const bool mono = st[b].mono != 0;
     const bool ring_grids = rcpairs != nullptr && st[b].ring_ok != 0;
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
     STAT_WAVE(2, 1);  // waves of lo_search_kernel
-    STAT_WAVE(22, ring_grids && mono ? 1 : 0);
     const PairDesc &CP = cpairs[b];
     const PairDesc &SP = spairs[b];
     const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off, *cl = clast + D.clast_off,
@@ -855,50 +867,29 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     int *si1 = ci2 + D.nc, *si2 = si1 + D.ns, *si3 = si2 + D.ns;
     // forward ring scans are bounded by the CURRENT sweep's feature counts (LO:620,776)
     const int fwd_c = min(D.nc, D.mc), fwd_s = min(D.ns, D.ms);
+    // joins two finished ring records: no candidate loses; else the smaller (d, ord)
+    auto better = [](float da, unsigned oa, int ia, float db, unsigned ob, int ib) -> int {
+        if (ia < 0) return ib;
+        if (ib < 0) return ia;
+        return (db < da || (db == da && ob < oa)) ? ib : ia;
+    };
     if (tile < ct) {
-        const int i = tile * PT_BLOCK + threadIdx.x;
+        const int i = tile * LO_TILE + lane;
         const bool act = i < D.nc;
         float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
         if (act) pi = sh[i];
         const float4 ps = lo_to_start(tr, pi);
-        int idx;
-        float sqd;
-        const int prev1 = act ? ci1[i] : -1, prev2 = act ? ci2[i] : -1;  // -1 in a sweep's first round (lo_init_kernel)
-#ifdef GPSCAL_STATS
-        const unsigned long long tk0 = wall_clock64();
-#endif
-        lo_nearest(CP, csorted, ccells, act, ps, idx, sqd, cl, prev1, slab);
-#ifdef GPSCAL_STATS
-        const unsigned long long tk1 = wall_clock64();
-        STAT_WAVE(19, tk1 - tk0);  // corner tiles: ticks (10 ns) in the nearest search
-        STAT_WAVE(9, 1);
-#endif
+        const int prev2 = act ? ci2[i] : -1;  // -1 in a sweep's first round (lo_init_kernel)
         int closest = -1, min2 = -1;
-        const bool has = act && idx >= 0 && sqd < 25;
-        if (has) closest = idx;
-        if (mono) {  // wave-uniform: the two walks as one search filtered to the adjacent rings
-            int a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-            if (has) {
-                const int scan = (int)cl[closest].w;
-                if (scan >= 1) {
-                    a0 = s_rs_c[scan - 1];
-                    a1 = s_rs_c[scan];
-                }
-                b0 = s_rs_c[scan + 1];
-                b1 = min(s_rs_c[scan + 2], fwd_c);
-            }
-            BestRing R;
-            R.init(25.f, closest, a0, a1, b0, b1);
-            ring_seed(R, has, cl, prev2, ps);
-            if (ring_grids) {
-                const int scan = has ? (int)cl[closest].w : -9;
-                ring_search(rcpairs + 16 * b, rcsorted, rccells, s_rs_c, has && a1 > a0, scan - 1, ps, R, slab);
-                ring_search(rcpairs + 16 * b, rcsorted, rccells, s_rs_c, has && b1 > b0, scan + 1, ps, R, slab);
-            } else {
-                knn_query(CP, csorted, ccells, has, ps.x, ps.y, ps.z, R, 0, slab);
-            }
-            if (has) min2 = R.i;
-        } else if (has) {
+        if (role == 0) {
+            int idx;
+            float sqd;
+            const int prev1 = act ? ci1[i] : -1;
+            lo_nearest(CP, csorted, ccells, act, ps, idx, sqd, cl, prev1, slab);
+            const bool has = act && idx >= 0 && sqd < 25;
+            if (has) closest = idx;
+            s_closest[lane] = closest;
+            if (!mono && has) {
             const int scan = (int)cl[closest].w;
             float d2min = 25;
             // the walks are sequential by definition (first strict minimum wins, stop at the
@@ -944,68 +935,57 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
                 }
             }
         }
-#ifdef GPSCAL_STATS
-        STAT_WAVE(20, wall_clock64() - tk1);  // ... and in the ring searches
-#endif
-        if (act) {
+        }
+        __syncthreads();
+        if (mono && (role == 1 || role == 2)) {  // the two walks as searches filtered to the adjacent rings
+            closest = s_closest[lane];
+            const bool has = closest >= 0;
+            int a0 = 0, a1 = 0, scan = -9;
+            if (has) {
+                scan = (int)cl[closest].w;
+                if (role == 1) {
+                    if (scan >= 1) {
+                        a0 = s_rs_c[scan - 1];
+                        a1 = s_rs_c[scan];
+                    }
+                } else {
+                    a0 = s_rs_c[scan + 1];
+                    a1 = min(s_rs_c[scan + 2], fwd_c);
+                }
+            }
+            BestRing R;
+            if (role == 1) R.init(25.f, closest, a0, a1, 0, 0);
+            else R.init(25.f, closest, 0, 0, a0, a1);
+            ring_seed(R, has, cl, prev2, ps);
+            if (ring_grids) ring_search(rcpairs + 16 * b, rcsorted, rccells, s_rs_c, has && a1 > a0, role == 1 ? scan - 1 : scan + 1, ps, R, slab);
+            else knn_query(CP, csorted, ccells, has && a1 > a0, ps.x, ps.y, ps.z, R, 0, slab);
+            s_rd[role][lane] = R.d;
+            s_ro[role][lane] = R.ord;
+            s_ri[role][lane] = has ? R.i : -1;
+        }
+        __syncthreads();
+        if (role == 0 && act) {
+            if (mono) min2 = better(s_rd[1][lane], s_ro[1][lane], s_ri[1][lane], s_rd[2][lane], s_ro[2][lane], s_ri[2][lane]);
             ci1[i] = closest;
             ci2[i] = min2;
         }
     } else {
-        const int i = (tile - ct) * PT_BLOCK + threadIdx.x;
+        const int i = (tile - ct) * LO_TILE + lane;
         const bool act = i < D.ns;
         float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
         if (act) pi = fl[i];
         const float4 ps = lo_to_start(tr, pi);
-        int idx;
-        float sqd;
-        const int prev1 = act ? si1[i] : -1, prev2 = act ? si2[i] : -1, prev3 = act ? si3[i] : -1;
-#ifdef GPSCAL_STATS
-        const unsigned long long tk0 = wall_clock64();
-#endif
-        lo_nearest(SP, ssorted, scells, act, ps, idx, sqd, sl, prev1, slab);
-#ifdef GPSCAL_STATS
-        const unsigned long long tk1 = wall_clock64();
-        STAT_WAVE(21, tk1 - tk0);  // surf tiles: nearest search
-        STAT_WAVE(10, 1);
-#endif
+        const int prev2 = act ? si2[i] : -1, prev3 = act ? si3[i] : -1;
         int closest = -1, min2 = -1, min3 = -1;
-        const bool has = act && idx >= 0 && sqd < 25;
-        if (has) closest = idx;
-        if (mono) {  // own ring -> min2, adjacent rings -> min3
-            int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, e0 = 0, e1 = 0;
-            if (has) {
-                const int scan = (int)sl[closest].w;
-                a0 = s_rs_s[scan];
-                a1 = closest;
-                b0 = closest + 1;
-                b1 = min(s_rs_s[scan + 1], fwd_s);
-                if (scan >= 1) {
-                    c0 = s_rs_s[scan - 1];
-                    c1 = s_rs_s[scan];
-                }
-                e0 = s_rs_s[scan + 1];
-                e1 = min(s_rs_s[scan + 2], fwd_s);
-            }
-            BestRing R2, R3;
-            R2.init(25.f, closest, a0, a1, b0, b1);
-            R3.init(25.f, closest, c0, c1, e0, e1);
-            ring_seed(R2, has, sl, prev2, ps);
-            ring_seed(R3, has, sl, prev3, ps);
-            if (ring_grids) {
-                const int scan = has ? (int)sl[closest].w : -9;
-                ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && (a1 > a0 || b1 > b0), scan, ps, R2, slab);
-                ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && c1 > c0, scan - 1, ps, R3, slab);
-                ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, has && e1 > e0, scan + 1, ps, R3, slab);
-            } else {
-                knn_query(SP, ssorted, scells, has, ps.x, ps.y, ps.z, R2, 0, slab);
-                knn_query(SP, ssorted, scells, has, ps.x, ps.y, ps.z, R3, 0, slab);
-            }
-            if (has) {
-                min2 = R2.i;
-                min3 = R3.i;
-            }
-        } else if (has) {
+        if (role == 0) {
+            int idx;
+            float sqd;
+            const int prev1 = act ? si1[i] : -1;
+            lo_nearest(SP, ssorted, scells, act, ps, idx, sqd, sl, prev1, slab);
+            const bool has = act && idx >= 0 && sqd < 25;
+            if (has) closest = idx;
+            s_closest[lane] = closest;
+            if (!mono && has) {
             const int scan = (int)sl[closest].w;
             float d2 = 25, d3 = 25;
             for (int j0 = closest + 1, stop = 0; j0 < fwd_s && !stop; j0 += RS) {
@@ -1051,10 +1031,48 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
                 }
             }
         }
-#ifdef GPSCAL_STATS
-        STAT_WAVE(23, wall_clock64() - tk1);  // surf tiles: ring searches
-#endif
-        if (act) {
+        }
+        __syncthreads();
+        if (mono && role >= 1) {  // own ring -> min2 (wave 1), adjacent rings -> min3 (waves 2 and 3)
+            closest = s_closest[lane];
+            const bool has = closest >= 0;
+            int a0 = 0, a1 = 0, b0 = 0, b1 = 0, scan = -9, want = -9;
+            if (has) {
+                scan = (int)sl[closest].w;
+                if (role == 1) {
+                    a0 = s_rs_s[scan];
+                    a1 = closest;
+                    b0 = closest + 1;
+                    b1 = min(s_rs_s[scan + 1], fwd_s);
+                    want = scan;
+                } else if (role == 2) {
+                    if (scan >= 1) {
+                        a0 = s_rs_s[scan - 1];
+                        a1 = s_rs_s[scan];
+                    }
+                    want = scan - 1;
+                } else {
+                    b0 = s_rs_s[scan + 1];
+                    b1 = min(s_rs_s[scan + 2], fwd_s);
+                    want = scan + 1;
+                }
+            }
+            BestRing R;
+            R.init(25.f, closest, a0, a1, b0, b1);
+            ring_seed(R, has, sl, role == 1 ? prev2 : prev3, ps);
+            const bool any = has && (a1 > a0 || b1 > b0);
+            if (ring_grids) ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, any, want, ps, R, slab);
+            else knn_query(SP, ssorted, scells, any, ps.x, ps.y, ps.z, R, 0, slab);
+            s_rd[role][lane] = R.d;
+            s_ro[role][lane] = R.ord;
+            s_ri[role][lane] = has ? R.i : -1;
+        }
+        __syncthreads();
+        if (role == 0 && act) {
+            if (mono) {
+                min2 = s_ri[1][lane];
+                min3 = better(s_rd[2][lane], s_ro[2][lane], s_ri[2][lane], s_rd[3][lane], s_ro[3][lane], s_ri[3][lane]);
+            }
             si1[i] = closest;
             si2[i] = min2;
             si3[i] = min3;
@@ -1316,11 +1334,12 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
     // entries may name the same sweep (two replay passes of one bag at the same message)
     std::vector<SweepDesc> hd(descs, descs + nsweeps);
     long long corr_total = 0;
-    int tiles_max = 1;
+    int tiles_max = 1, search_tiles = 1;
     for (int b = 0; b < nsweeps; ++b) {
         hd[b].corr_off = corr_total;
         corr_total += 2ll * hd[b].nc + 3ll * hd[b].ns;
         tiles_max = std::max(tiles_max, div_up(hd[b].nc, PT_BLOCK) + div_up(hd[b].ns, PT_BLOCK));
+        search_tiles = std::max(search_tiles, div_up(hd[b].nc, LO_TILE) + div_up(hd[b].ns, LO_TILE));
     }
     DevBuf<SweepDesc> d_sw;
     DevBuf<IterState> d_st;
@@ -1336,7 +1355,7 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
     hipLaunchKernelGGL(loam_stat_slot_kernel, dim3(1), dim3(1), 0, ctx->stream, 1);
 #endif
     for (int it0 = 0; it0 < 25; it0 += 5) {  // LO:585: a search every fifth iteration (LO:592)
-        hipLaunchKernelGGL(lo_search_kernel, dim3(tiles_max, nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_sharp,
+        hipLaunchKernelGGL(lo_search_kernel, dim3(search_tiles, nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_sharp,
                            d_flat, d_clast, d_slast, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p,
                            sg.cell_start, corr.p, d_st.p, ring_grids ? rcg.pairs.p : nullptr, rcg.sorted.p, rcg.cell_start,
                            ring_grids ? rsg.pairs.p : nullptr, rsg.sorted.p, rsg.cell_start);
