@@ -44,13 +44,17 @@ __device__ __forceinline__ float4 lo_to_start(const float *tr, float4 p)
     const float s = 10 * (p.w - (int)p.w);
     const float rx = s * tr[0], ry = s * tr[1], rz = s * tr[2];
     const float tx = s * tr[3], ty = s * tr[4], tz = s * tr[5];
-    const float x1 = cosf(rz) * (p.x - tx) + sinf(rz) * (p.y - ty);
-    const float y1 = -sinf(rz) * (p.x - tx) + cosf(rz) * (p.y - ty);
+    float sz, cz, sx, cx, sy, cy;  // per point: the angles scale with the point's relative time
+    sincosf(rz, &sz, &cz);
+    sincosf(rx, &sx, &cx);
+    sincosf(ry, &sy, &cy);
+    const float x1 = cz * (p.x - tx) + sz * (p.y - ty);
+    const float y1 = -sz * (p.x - tx) + cz * (p.y - ty);
     const float z1 = (p.z - tz);
     const float x2 = x1;
-    const float y2 = cosf(rx) * y1 + sinf(rx) * z1;
-    const float z2 = -sinf(rx) * y1 + cosf(rx) * z1;
-    return make_float4(cosf(ry) * x2 - sinf(ry) * z2, y2, sinf(ry) * x2 + cosf(ry) * z2, p.w);
+    const float y2 = cx * y1 + sx * z1;
+    const float z2 = -sx * y1 + cx * z1;
+    return make_float4(cy * x2 - sy * z2, y2, sy * x2 + cy * z2, p.w);
 }
 
 __device__ __forceinline__ float4 lo_to_end(const float *tr, float4 p)
@@ -76,10 +80,23 @@ __device__ __forceinline__ float sq3(float4 a, float4 b)
 }
 
 // One row of the linearised system (LO:916-971, s = 1): Jacobian a[6] and b = -0.05 d2.
-__device__ __forceinline__ void lo_row(const float *tr, float4 pt, float4 cf, double *sum)
+// sines / cosines of the current transform: the same for every row of an iteration (computing them per row, as
+// the expression reads, was a third of lo_iter_kernel's instructions)
+struct LoTrig {
+    float srx, crx, sry, cry, srz, crz, tx, ty, tz;
+    __device__ __forceinline__ void set(const float *tr)
+    {
+        srx = sinf(tr[0]); crx = cosf(tr[0]);
+        sry = sinf(tr[1]); cry = cosf(tr[1]);
+        srz = sinf(tr[2]); crz = cosf(tr[2]);
+        tx = tr[3]; ty = tr[4]; tz = tr[5];
+    }
+};
+
+__device__ __forceinline__ void lo_row(const LoTrig &g, float4 pt, float4 cf, double *sum)
 {
-    const float srx = sinf(tr[0]), crx = cosf(tr[0]), sry = sinf(tr[1]), cry = cosf(tr[1]);
-    const float srz = sinf(tr[2]), crz = cosf(tr[2]), tx = tr[3], ty = tr[4], tz = tr[5];
+    const float srx = g.srx, crx = g.crx, sry = g.sry, cry = g.cry;
+    const float srz = g.srz, crz = g.crz, tx = g.tx, ty = g.ty, tz = g.tz;
     const float px = pt.x, py = pt.y, pz = pt.z, cx = cf.x, cy = cf.y, cz = cf.z;
     float a[6];
     a[0] = (-crx * sry * srz * px + crx * crz * sry * py + srx * sry * pz + tx * crx * sry * srz - ty * crx * crz * sry -
@@ -828,7 +845,7 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     const float4 *__restrict__ ssorted, const unsigned *__restrict__ scells, int *__restrict__ corr,
     const IterState *__restrict__ st, const PairDesc *__restrict__ rcpairs, const float4 *__restrict__ rcsorted,
     const unsigned *__restrict__ rccells, const PairDesc *__restrict__ rspairs, const float4 *__restrict__ rssorted,
-    const unsigned *__restrict__ rscells)
+    const unsigned *__restrict__ rscells, float4 *__restrict__ geo)
 {
     static_assert(PT_BLOCK == 4 * LO_TILE, "four waves per tile of 64 features");
     const int b = blockIdx.y;
@@ -968,6 +985,17 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
             if (mono) min2 = better(s_rd[1][lane], s_ro[1][lane], s_ri[1][lane], s_rd[2][lane], s_ro[2][lane], s_ri[2][lane]);
             ci1[i] = closest;
             ci2[i] = min2;
+            // what the five iterations up to the next search need of this correspondence: the two points of the line
+            // (the iteration kernel then reads two coalesced streams instead of chasing two indices per feature)
+            float4 g1 = make_float4(0.f, 0.f, 0.f, 0.f), g2 = g1;
+            if (closest >= 0 && min2 >= 0) {
+                const float4 t1 = cl[closest], t2 = cl[min2];
+                g1 = make_float4(t1.x, t1.y, t1.z, 1.f);
+                g2 = make_float4(t2.x, t2.y, t2.z, 0.f);
+            }
+            float4 *gc = geo + D.corr_off;
+            gc[2 * i] = g1;
+            gc[2 * i + 1] = g2;
         }
     } else {
         const int i = (tile - ct) * LO_TILE + lane;
@@ -1076,6 +1104,19 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
             si1[i] = closest;
             si2[i] = min2;
             si3[i] = min3;
+            // ... and the unit plane through the three points (LO:847-870), which no iteration changes
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);  // without a full correspondence: pd2 = 0, no row
+            if (closest >= 0 && min2 >= 0 && min3 >= 0) {
+                const float4 t1 = sl[closest], t2 = sl[min2], t3 = sl[min3];
+                float pa = (t2.y - t1.y) * (t3.z - t1.z) - (t3.y - t1.y) * (t2.z - t1.z);
+                float pb = (t2.z - t1.z) * (t3.x - t1.x) - (t3.z - t1.z) * (t2.x - t1.x);
+                float pc = (t2.x - t1.x) * (t3.y - t1.y) - (t3.x - t1.x) * (t2.y - t1.y);
+                float pd = -(pa * t1.x + pb * t1.y + pc * t1.z);
+                const float pn = sqrtf(pa * pa + pb * pb + pc * pc);
+                pa /= pn; pb /= pn; pc /= pn; pd /= pn;
+                g = make_float4(pa, pb, pc, pd);
+            }
+            geo[D.corr_off + 2 * (long long)D.nc + i] = g;
         }
     }
 }
@@ -1084,7 +1125,7 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
 __global__ __launch_bounds__(LBLOCK) void lo_iter_kernel(
     const SweepDesc *__restrict__ sweeps, const float4 *__restrict__ sharp, const float4 *__restrict__ flat,
     const float4 *__restrict__ clast, const float4 *__restrict__ slast, const int *__restrict__ corr,
-    IterState *__restrict__ st, int it0)
+    IterState *__restrict__ st, int it0, const float4 *__restrict__ geo)
 {
     const int b = blockIdx.x;
     IterState &S = st[b];
@@ -1093,10 +1134,8 @@ __global__ __launch_bounds__(LBLOCK) void lo_iter_kernel(
     __shared__ double red[LWAVES][LSUMS];
     __shared__ int s_done;
     const SweepDesc D = sweeps[b];
-    const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off, *cl = clast + D.clast_off,
-                 *sl = slast + D.slast_off;
-    const int *ci1 = corr + D.corr_off, *ci2 = ci1 + D.nc;
-    const int *si1 = ci2 + D.nc, *si2 = si1 + D.ns, *si3 = si2 + D.ns;
+    const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off;
+    const float4 *gc = geo + D.corr_off, *gs = gc + 2 * (long long)D.nc;  // lo_search_kernel: line points | planes
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 6) tr[threadIdx.x] = S.tr[threadIdx.x];
     if (threadIdx.x == 0) s_done = 0;
@@ -1105,6 +1144,8 @@ __global__ __launch_bounds__(LBLOCK) void lo_iter_kernel(
         double sum[LSUMS];
 #pragma unroll
         for (int k = 0; k < LSUMS; ++k) sum[k] = 0.0;
+        LoTrig g;
+        g.set(tr);
         // ---- corner features: point-to-line (LO:680-746)
         for (int i0 = 0; i0 < D.nc; i0 += LBLOCK) {
             const int i = i0 + threadIdx.x;
@@ -1112,8 +1153,12 @@ __global__ __launch_bounds__(LBLOCK) void lo_iter_kernel(
             float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
             if (act) pi = sh[i];
             const float4 ps = lo_to_start(tr, pi);
-            if (act && ci2[i] >= 0) {
-                const float4 t1 = cl[ci1[i]], t2 = cl[ci2[i]];
+            float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+            if (act) {
+                t1 = gc[2 * i];
+                t2 = gc[2 * i + 1];
+            }
+            if (act && t1.w != 0.f) {  // a full correspondence (lo_search_kernel)
                 const float x0 = ps.x, y0 = ps.y, z0 = ps.z;
                 const float x1 = t1.x, y1 = t1.y, z1 = t1.z, x2 = t2.x, y2 = t2.y, z2 = t2.z;
                 const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
@@ -1127,7 +1172,7 @@ __global__ __launch_bounds__(LBLOCK) void lo_iter_kernel(
                 const float ld2 = a012 / l12;
                 float s = 1;
                 if (it >= 5) s = (float)(1 - 1.8 * fabs((double)ld2));
-                if (s > 0.1 && ld2 != 0) lo_row(tr, pi, make_float4(s * la, s * lb, s * lc, s * ld2), sum);
+                if (s > 0.1 && ld2 != 0) lo_row(g, pi, make_float4(s * la, s * lb, s * lc, s * ld2), sum);
             }
         }
         // ---- surface features: point-to-plane (LO:847-901)
@@ -1137,19 +1182,15 @@ __global__ __launch_bounds__(LBLOCK) void lo_iter_kernel(
             float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
             if (act) pi = fl[i];
             const float4 ps = lo_to_start(tr, pi);
-            if (act && si2[i] >= 0 && si3[i] >= 0) {
-                const float4 t1 = sl[si1[i]], t2 = sl[si2[i]], t3 = sl[si3[i]];
-                float pa = (t2.y - t1.y) * (t3.z - t1.z) - (t3.y - t1.y) * (t2.z - t1.z);
-                float pb = (t2.z - t1.z) * (t3.x - t1.x) - (t3.z - t1.z) * (t2.x - t1.x);
-                float pc = (t2.x - t1.x) * (t3.y - t1.y) - (t3.x - t1.x) * (t2.y - t1.y);
-                float pd = -(pa * t1.x + pb * t1.y + pc * t1.z);
-                const float pn = sqrtf(pa * pa + pb * pb + pc * pc);
-                pa /= pn; pb /= pn; pc /= pn; pd /= pn;
+            float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act) pl = gs[i];  // the unit plane of the correspondence; zeros without one
+            if (act && (pl.x != 0.f || pl.y != 0.f || pl.z != 0.f || pl.w != 0.f)) {
+                const float pa = pl.x, pb = pl.y, pc = pl.z, pd = pl.w;
                 const float pd2 = pa * ps.x + pb * ps.y + pc * ps.z + pd;
                 float s = 1;
                 if (it >= 5)
                     s = (float)(1 - 1.8 * fabs((double)pd2) / (double)sqrtf(sqrtf(ps.x * ps.x + ps.y * ps.y + ps.z * ps.z)));
-                if (s > 0.1 && pd2 != 0) lo_row(tr, pi, make_float4(s * pa, s * pb, s * pc, s * pd2), sum);
+                if (s > 0.1 && pd2 != 0) lo_row(g, pi, make_float4(s * pa, s * pb, s * pc, s * pd2), sum);
             }
         }
         // ---- block reduction of the 28 sums (fixed order)
@@ -1347,6 +1388,8 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
     GPSCAL_HIP(ctx, d_sw.alloc_async(nsweeps, ctx->stream));
     GPSCAL_HIP(ctx, d_st.alloc_async(nsweeps, ctx->stream));
     GPSCAL_HIP(ctx, corr.alloc_async((size_t)corr_total + 8, ctx->stream));
+    DevBuf<float4> geo;  // per feature: the line points (2 float4 per sharp point) | the plane (1 per flat point), at corr_off
+    GPSCAL_HIP(ctx, geo.alloc_async((size_t)corr_total + 8, ctx->stream));
     descs = hd.data();
     GPSCAL_HIP(ctx, hipMemcpyAsync(d_sw.p, descs, sizeof(SweepDesc) * nsweeps, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(lo_init_kernel, dim3(nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_clast, d_slast, corr.p,
@@ -1358,9 +1401,9 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
         hipLaunchKernelGGL(lo_search_kernel, dim3(search_tiles, nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_sharp,
                            d_flat, d_clast, d_slast, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p,
                            sg.cell_start, corr.p, d_st.p, ring_grids ? rcg.pairs.p : nullptr, rcg.sorted.p, rcg.cell_start,
-                           ring_grids ? rsg.pairs.p : nullptr, rsg.sorted.p, rsg.cell_start);
+                           ring_grids ? rsg.pairs.p : nullptr, rsg.sorted.p, rsg.cell_start, geo.p);
         hipLaunchKernelGGL(lo_iter_kernel, dim3(nsweeps), dim3(LBLOCK), 0, ctx->stream, d_sw.p, d_sharp, d_flat,
-                           d_clast, d_slast, corr.p, d_st.p, it0);
+                           d_clast, d_slast, corr.p, d_st.p, it0, geo.p);
     }
     hipLaunchKernelGGL(lo_finish_kernel, dim3(div_up(nsweeps, 64)), dim3(64), 0, ctx->stream, d_st.p, nsweeps, d_tr_out,
                        d_iters, d_nsel, d_sum_in, d_sum_out);
