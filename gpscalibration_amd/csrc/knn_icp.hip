@@ -27,6 +27,7 @@
 #include "wave_reduce.hpp"
 
 #include <algorithm>
+#include <deque>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -35,18 +36,21 @@ namespace gpscal {
 
 // --------------------------------------------------------------- build path
 
+// `raw` holds the `total` points of pairs offs[0 .. npairs] (offs[0] = the position of its first point in `out`:
+// several sources may fill one packed array one after the other).
 __global__ void pack_points_kernel(const char *__restrict__ raw, int stride, const long long *__restrict__ offs,
                                    int npairs, long long total, float4 *__restrict__ out)
 {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= total) return;
+    const long long i = offs[0] + r;
     // pair of point i: last b with offs[b] <= i
     int lo = 0, hi = npairs;
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
         if (offs[mid] <= i) lo = mid; else hi = mid;
     }
-    const float *p = reinterpret_cast<const float *>(raw + (size_t)i * stride);
+    const float *p = reinterpret_cast<const float *>(raw + (size_t)r * stride);
     out[i] = make_float4(p[0], p[1], p[2], __int_as_float((int)(i - offs[lo])));
 }
 
@@ -737,23 +741,50 @@ static void plan_levels(const float mn[3], const float mx[3], int m, float cell,
 
 // Grid sets for several clouds-of-clouds at once (the LOAM nodes index two to four of them per sweep): the
 // bounding boxes of all of them come back in ONE read-back, which is the only point where the host waits --
-// the grid dimensions are planned on the host.  Pooled sets (per-call sets of the LOAM chain) are not
-// synchronised at the end either: their temporaries go back to the stream's block cache in stream order.
+// the grid dimensions are planned on the host.  Sources that name the SAME GridSet are concatenated into it (source
+// k's pairs follow source k-1's; positions and cell numbers are the set's own, so a consumer addresses a source's
+// pairs as set.pairs + its first pair and shares sorted / cell_start): four index sets then cost the launches of
+// one.  Pooled sets (per-call sets of the LOAM chain) are not synchronised at the end either: their temporaries go
+// back to the stream's block cache in stream order.
 int build_grids_multi(gpscal_ctx *ctx, int nsrc, const GridSource *src, int stride, float cell, int max_levels)
 {
     if (stride < 12) return fail(ctx, GPSCAL_EINVAL, "stride_bytes must be >= 12");
-    struct Part {
-        std::vector<long long> rel;
+    struct Part {  // one distinct GridSet
+        GridSet *gs = nullptr;
+        std::vector<int> srcs;
+        std::vector<long long> rel;   // npairs + 1 positions in the set's packed array
+        std::vector<float> cells;     // per pair: its source's cell size hint
         DevBuf<long long> d_off;
-        InArg<char> raw;
         long long total = 0, bbox_at = 0;
-        int mmax = 0;
+        int npairs = 0, mmax = 0;
     };
-    std::vector<Part> parts(nsrc);
-    long long nbox = 0;
+    std::deque<Part> parts;  // (DevBuf members: no relocation)
     for (int k = 0; k < nsrc; ++k) {
-        parts[k].bbox_at = nbox;
-        nbox += src[k].npairs;
+        Part *W = nullptr;
+        for (auto &q : parts)
+            if (q.gs == src[k].gs) W = &q;
+        if (!W) {
+            parts.emplace_back();
+            W = &parts.back();
+            W->gs = src[k].gs;
+            W->rel.push_back(0);
+        }
+        W->srcs.push_back(k);
+        const long long *off = src[k].off;
+        for (int b = 0; b < src[k].npairs; ++b) {
+            const long long m = off[b + 1] - off[b];
+            if (m < 0 || m > 0x7fffffff) return fail(ctx, GPSCAL_EINVAL, "bad offsets");
+            W->rel.push_back(W->rel.back() + m);
+            W->cells.push_back(src[k].cell != 0.f ? src[k].cell : cell);
+            W->mmax = std::max(W->mmax, (int)m);
+        }
+        W->npairs += src[k].npairs;
+    }
+    long long nbox = 0;
+    for (auto &W : parts) {
+        W.total = W.rel.back();
+        W.bbox_at = nbox;
+        nbox += W.npairs;
     }
     DevBuf<int> d_bbox;
     GPSCAL_HIP(ctx, d_bbox.alloc_async((size_t)std::max<long long>(nbox, 1) * 6, ctx->stream));
@@ -764,46 +795,40 @@ int build_grids_multi(gpscal_ctx *ctx, int nsrc, const GridSource *src, int stri
             hb[b * 6 + 3 + a] = (int)0x80000000;
         }
     GPSCAL_HIP(ctx, hipMemcpyAsync(d_bbox.p, hb.data(), sizeof(int) * hb.size(), hipMemcpyHostToDevice, ctx->stream));
-    for (int k = 0; k < nsrc; ++k) {
-        GridSet &gs = *src[k].gs;
-        Part &W = parts[k];
-        const long long *off = src[k].off;
-        const int npairs = src[k].npairs;
+    std::vector<InArg<char> > raws(nsrc);
+    for (auto &W : parts) {
+        GridSet &gs = *W.gs;
         gs.ctx = ctx;
-        gs.npairs = npairs;
-        gs.off.assign(off, off + npairs + 1);
-        W.total = off[npairs] - off[0];
-        if (W.total < 0) return fail(ctx, GPSCAL_EINVAL, "negative point count");
-        GPSCAL_HIP(ctx, W.raw.bind(ctx, static_cast<const char *>(src[k].xyz) + (size_t)off[0] * stride,
-                                   (size_t)W.total * stride));
+        gs.npairs = W.npairs;
+        gs.off = W.rel;
         GPSCAL_HIP(ctx, gs.pooled ? gs.pts4.alloc_async((size_t)W.total, ctx->stream) : gs.pts4.alloc((size_t)W.total));
-        GPSCAL_HIP(ctx, W.d_off.alloc_async(npairs + 1, ctx->stream));
-        W.rel.resize(npairs + 1);
-        for (int b = 0; b <= npairs; ++b) W.rel[b] = off[b] - off[0];
-        GPSCAL_HIP(ctx, hipMemcpyAsync(W.d_off.p, W.rel.data(), sizeof(long long) * (npairs + 1), hipMemcpyHostToDevice,
+        GPSCAL_HIP(ctx, W.d_off.alloc_async(W.npairs + 1, ctx->stream));
+        GPSCAL_HIP(ctx, hipMemcpyAsync(W.d_off.p, W.rel.data(), sizeof(long long) * (W.npairs + 1), hipMemcpyHostToDevice,
                                        ctx->stream));
-        for (int b = 0; b < npairs; ++b) {
-            long long m = W.rel[b + 1] - W.rel[b];
-            if (m < 0 || m > 0x7fffffff) return fail(ctx, GPSCAL_EINVAL, "bad offsets");
-            W.mmax = std::max(W.mmax, (int)m);
+        int pb = 0;
+        for (int k : W.srcs) {
+            const long long *off = src[k].off;
+            const long long tk = off[src[k].npairs] - off[0];
+            GPSCAL_HIP(ctx, raws[k].bind(ctx, static_cast<const char *>(src[k].xyz) + (size_t)off[0] * stride,
+                                         (size_t)tk * stride));
+            if (tk > 0)
+                hipLaunchKernelGGL(pack_points_kernel, dim3(div_up(tk, BLOCK)), dim3(BLOCK), 0, ctx->stream, raws[k].dev,
+                                   stride, W.d_off.p + pb, src[k].npairs, tk, gs.pts4.p);
+            pb += src[k].npairs;
         }
-        if (W.total > 0)
-            hipLaunchKernelGGL(pack_points_kernel, dim3(div_up(W.total, BLOCK)), dim3(BLOCK), 0, ctx->stream, W.raw.dev,
-                               stride, W.d_off.p, npairs, W.total, gs.pts4.p);
         // bounding boxes
         const int gx = std::max(1, std::min(div_up(W.mmax, BLOCK * 4), 256));
-        if (npairs > 0 && W.mmax > 0)
-            hipLaunchKernelGGL(bbox_kernel, dim3(gx, npairs), dim3(BLOCK), 0, ctx->stream, gs.pts4.p, W.d_off.p,
+        if (W.npairs > 0 && W.mmax > 0)
+            hipLaunchKernelGGL(bbox_kernel, dim3(gx, W.npairs), dim3(BLOCK), 0, ctx->stream, gs.pts4.p, W.d_off.p,
                                d_bbox.p + W.bbox_at * 6);
     }
     GPSCAL_HIP(ctx, hipMemcpyAsync(hb.data(), d_bbox.p, sizeof(int) * hb.size(), hipMemcpyDeviceToHost, ctx->stream));
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
     bool all_pooled = true;
-    for (int k = 0; k < nsrc; ++k) {
-        GridSet &gs = *src[k].gs;
-        Part &W = parts[k];
-        const int npairs = src[k].npairs;
+    for (auto &W : parts) {
+        GridSet &gs = *W.gs;
+        const int npairs = W.npairs;
         const std::vector<long long> &rel = W.rel;
         const int *hbk = hb.data() + W.bbox_at * 6;
         all_pooled = all_pooled && gs.pooled;
@@ -819,7 +844,7 @@ int build_grids_multi(gpscal_ctx *ctx, int nsrc, const GridSource *src, int stri
                 mx[a] = ord2f(hbk[b * 6 + 3 + a]);
                 if (!(mn[a] <= mx[a])) mn[a] = mx[a] = 0.f;  // empty / all-NaN cloud
             }
-            plan_levels(mn, mx, P.m, src[k].cell != 0.f ? src[k].cell : cell, max_levels, P);
+            plan_levels(mn, mx, P.m, W.cells[b], max_levels, P);
             // levels whose cells (counted from the top) fit the LDS histogram are aggregated there
             {
                 long long acc = 0;

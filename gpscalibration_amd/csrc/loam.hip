@@ -1329,12 +1329,11 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
                          const long long *soff, const float *d_tr_in, float *d_tr_out, int *d_iters, int *d_nsel,
                          const float *d_sum_in, float *d_sum_out, const int *ring_cnt_c, const int *ring_cnt_s)
 {
-    // the kd-trees of the last sweep (setInputCloud, LO:538-539,1119-1120) = two grid sets
-    GridSet cg, sg;
-    cg.pooled = sg.pooled = pool_grids();
-    // one more grid per ring of each last cloud for the adjacent-ring searches (LO:613-677, 769-844)
-    GridSet rcg, rsg;
-    rcg.pooled = rsg.pooled = pool_grids();
+    // the kd-trees of the last sweep (setInputCloud, LO:538-539,1119-1120) = two index sets, and one more grid per
+    // ring of each last cloud for the adjacent-ring searches (LO:613-677, 769-844) -- all in ONE GridSet: the four
+    // sources are concatenated (build_grids_multi), which makes their ~40 small launches ~12
+    GridSet all;
+    all.pooled = pool_grids();
     DevBuf<int> d_ringc, d_rings;
     bool ring_grids = ring_cnt_c && ring_cnt_s;
     std::vector<long long> roc, ros;
@@ -1358,13 +1357,16 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
         // all four index sets in one call: one host wait (their bounding boxes) instead of four
         // (the per-ring grids keep the even-surface cell size although a ring is a curve: its level 0 then
         // covers laserOdometry's 5 m radius in one pass; 10x / 100x / 1000x finer cells were measured 2 % / 10 % / 64 % slower)
-        GridSource srcs[4] = {{d_clast, coff, nsweeps, &cg, 0.f},
-                              {d_slast, soff, nsweeps, &sg, 0.f},
-                              {d_clast, roc.data(), nsweeps * 16, &rcg, 0.f},
-                              {d_slast, ros.data(), nsweeps * 16, &rsg, 0.f}};
+        GridSource srcs[4] = {{d_clast, coff, nsweeps, &all, 0.f},
+                              {d_slast, soff, nsweeps, &all, 0.f},
+                              {d_clast, roc.data(), nsweeps * 16, &all, 0.f},
+                              {d_slast, ros.data(), nsweeps * 16, &all, 0.f}};
         int rc = build_grids_multi(ctx, ring_grids ? 4 : 2, srcs, 16, 0.f, MAX_LEVELS);
         if (rc) return rc;
     }
+    // a source's pairs inside the set: corner clouds | surf clouds | corner rings | surf rings
+    const PairDesc *cgp = all.pairs.p, *sgp = all.pairs.p + nsweeps, *rcgp = all.pairs.p + 2 * (size_t)nsweeps,
+                   *rsgp = all.pairs.p + 18 * (size_t)nsweeps;
     if (ring_grids) {
         GPSCAL_HIP(ctx, d_ringc.alloc_async((size_t)nsweeps * 16, ctx->stream));
         GPSCAL_HIP(ctx, d_rings.alloc_async((size_t)nsweeps * 16, ctx->stream));
@@ -1399,9 +1401,9 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
 #endif
     for (int it0 = 0; it0 < 25; it0 += 5) {  // LO:585: a search every fifth iteration (LO:592)
         hipLaunchKernelGGL(lo_search_kernel, dim3(search_tiles, nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_sharp,
-                           d_flat, d_clast, d_slast, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p,
-                           sg.cell_start, corr.p, d_st.p, ring_grids ? rcg.pairs.p : nullptr, rcg.sorted.p, rcg.cell_start,
-                           ring_grids ? rsg.pairs.p : nullptr, rsg.sorted.p, rsg.cell_start, geo.p);
+                           d_flat, d_clast, d_slast, cgp, all.sorted.p, all.cell_start, sgp, all.sorted.p,
+                           all.cell_start, corr.p, d_st.p, ring_grids ? rcgp : nullptr, all.sorted.p, all.cell_start,
+                           ring_grids ? rsgp : nullptr, all.sorted.p, all.cell_start, geo.p);
         hipLaunchKernelGGL(lo_iter_kernel, dim3(nsweeps), dim3(LBLOCK), 0, ctx->stream, d_sw.p, d_sharp, d_flat,
                            d_clast, d_slast, corr.p, d_st.p, it0, geo.p);
     }
@@ -1480,13 +1482,14 @@ int loam_mapping_device(gpscal_ctx *ctx, int nsweeps, const MapDesc *descs, cons
                         const long long *smoff, const float *d_tr_in, float *d_tr_out, int *d_iters, int *d_nsel)
 {
     // kdtreeCornerFromMap / kdtreeSurfFromMap (setInputCloud, LM:749-750) = two grid sets
-    GridSet cg, sg;
-    cg.pooled = sg.pooled = pool_grids();
+    GridSet all;  // both in one set (concatenated sources): corner maps | surf maps
+    all.pooled = pool_grids();
     {
-        GridSource srcs[2] = {{d_cmap, cmoff, nsweeps, &cg, 0.f}, {d_smap, smoff, nsweeps, &sg, 0.f}};
+        GridSource srcs[2] = {{d_cmap, cmoff, nsweeps, &all, 0.f}, {d_smap, smoff, nsweeps, &all, 0.f}};
         int rc = build_grids_multi(ctx, 2, srcs, 16, 0.f, MAX_LEVELS);
         if (rc) return rc;
     }
+    const PairDesc *cgp = all.pairs.p, *sgp = all.pairs.p + nsweeps;
     DevBuf<MapDesc> d_sw;
     DevBuf<IterState> d_st;
     DevBuf<double> d_part;
@@ -1511,8 +1514,8 @@ int loam_mapping_device(gpscal_ctx *ctx, int nsweeps, const MapDesc *descs, cons
 #endif
     for (int it = 0; it < 10; ++it) {  // LM:752; converged sweeps return at once
         hipLaunchKernelGGL(lm_point_kernel, dim3(tiles_max, nsweeps), dim3(PT_BLOCK), 0, ctx->stream, d_sw.p, d_cstack,
-                           d_sstack, d_cmap, d_smap, cg.pairs.p, cg.sorted.p, cg.cell_start, sg.pairs.p, sg.sorted.p,
-                           sg.cell_start, d_st.p, d_part.p, tiles_max, d_prev5.p, ext_c);
+                           d_sstack, d_cmap, d_smap, cgp, all.sorted.p, all.cell_start, sgp, all.sorted.p,
+                           all.cell_start, d_st.p, d_part.p, tiles_max, d_prev5.p, ext_c);
         hipLaunchKernelGGL(lm_solve_kernel, dim3(nsweeps), dim3(64), 0, ctx->stream, d_sw.p, d_st.p, d_part.p,
                            tiles_max, it);
     }
