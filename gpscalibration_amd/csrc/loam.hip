@@ -1357,6 +1357,7 @@ int loam_odometry_device(gpscal_ctx *ctx, int nsweeps, const SweepDesc *descs, c
         // all four index sets in one call: one host wait (their bounding boxes) instead of four
         // (the per-ring grids keep the even-surface cell size although a ring is a curve: its level 0 then
         // covers laserOdometry's 5 m radius in one pass; 10x / 100x / 1000x finer cells were measured 2 % / 10 % / 64 % slower)
+        // (the two cloud sets as well: 1.5 / 0.75 / 0.4 / 0.2 points per cell instead of 3: +2 / 0 / -2 / -8 %)
         GridSource srcs[4] = {{d_clast, coff, nsweeps, &all, 0.f},
                               {d_slast, soff, nsweeps, &all, 0.f},
                               {d_clast, roc.data(), nsweeps * 16, &all, 0.f},
