@@ -519,6 +519,27 @@ def test_icp_two_builds_are_bit_identical(ctx):
     b.close()
 
 
+def test_icp_run_in_two_calls_equals_one_call(ctx):
+    """A run may be continued: icp(8) followed by icp(12) is the 20-iteration run, bit for bit (poses and final
+    correspondences), and alternating between iteration counts keeps one captured graph per count -- the third and
+    fourth calls below replay the graphs of the first two."""
+    tg, to, sr, so, _ = synth.scan_batch(9, 8192)
+    one = ctx.scan_batch(tg, to, sr, so)
+    T20, _, _ = one.icp(20)
+    c20 = one.correspondences()
+    two = ctx.scan_batch(tg, to, sr, so)
+    two.icp(8)
+    Tb, _, _ = two.icp(12)
+    assert np.array_equal(T20, Tb)
+    assert all(np.array_equal(a, b) for a, b in zip(c20, two.correspondences()))
+    two.set_pose(None)
+    two.icp(8)
+    Tc, _, _ = two.icp(12)
+    assert np.array_equal(T20, Tc)
+    one.close()
+    two.close()
+
+
 # -------------------------------------------------------------------- track
 def _segments(nseg, poses, seed, dropout=0.0):
     d = synth.track_segments(nseg, poses, seed=seed, dropout=dropout)
