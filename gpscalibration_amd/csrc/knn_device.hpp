@@ -457,8 +457,10 @@ template <class BT>
 __device__ __forceinline__ void block3_level_flat(const GridDesc &G, const CellGeo &C,
                                                   const float4 *__restrict__ sorted,
                                                   const unsigned *__restrict__ cell_start, bool act, float px,
-                                                  float py, float pz, BT &B, uint2 *__restrict__ slab)
+                                                  float py, float pz, BT &B, uint2 *__restrict__ slab,
+                                                  unsigned rows = 0x1ffu)
 {
+    // rows: bit r = visit row r (0 = the own row): several waves may share one query's block, each with its rows
     const float mg = G.margin;
     const float bxl = fmaxf(C.fx0 - mg, 0.f), bxr = fmaxf(C.fx1 - mg, 0.f);
     const float bxl2 = bxl * bxl, bxr2 = bxr * bxr;
@@ -472,7 +474,7 @@ __device__ __forceinline__ void block3_level_flat(const GridDesc &G, const CellG
     const int lane = threadIdx.x & 63;
     const long long own = G.cell_base + ((long long)C.cz * G.ny + C.cy) * G.nx + C.cx;
     const long long dyo = G.nx, dzo = (long long)G.ny * G.nx;
-    {  // the own row
+    if (rows & 1u) {  // the own row
         CellQuad q = {0u, 0u, 0u, 0u};
         if (act) q = *reinterpret_cast<const CellQuad *>(cell_start + own - 1);
         const unsigned c0 = has_l ? q.a : q.b, c1 = q.b, c2 = q.c, c3 = has_r ? q.d : q.c;
@@ -489,7 +491,7 @@ __device__ __forceinline__ void block3_level_flat(const GridDesc &G, const CellG
 #pragma unroll
         for (int t = 0; t < FLAT_BATCH; ++t) {
             const int r = 1 + half * FLAT_BATCH + t, kz = r / 3, ky = r - 3 * kz;
-            p[t] = act && yok[ky] && zok[kz] && (by2[ky] + bz2[kz]) * 0.99999f <= B.worst();
+            p[t] = act && ((rows >> r) & 1u) && yok[ky] && zok[kz] && (by2[ky] + bz2[kz]) * 0.99999f <= B.worst();
             q[t] = CellQuad{0u, 0u, 0u, 0u};
             if (p[t]) {
                 const long long row = own + (ky == 0 ? 0 : (ky == 1 ? -dyo : dyo)) + (kz == 0 ? 0 : (kz == 1 ? -dzo : dzo));

@@ -831,6 +831,65 @@ __device__ __forceinline__ void ring_seed(BestRing &R, bool has, const float4 *_
     }
 }
 
+// The nearest search of a tile's 64 features by all four waves of its workgroup: every wave holds the same 64
+// queries and takes some of the 3x3x3 block's nine rows (rows 0-2 | 3-4 | 5-6 | 7-8); after each level the waves join
+// their records through LDS (smaller squared distance, then smaller index: the record's own order), so that all of
+// them decide together whether the level settled the query.  Must be called by the whole workgroup; `act`, `p` and
+// the seed are the same in every wave.  One wave walking all nine rows was the longest chain of the kernel.
+__device__ __forceinline__ void lo_nearest_split(const PairDesc &P, const float4 *__restrict__ sorted,
+                                                 const unsigned *__restrict__ cell_start, bool act, float4 p, int &idx,
+                                                 float &sqd, const float4 *__restrict__ cloud, int seed,
+                                                 uint2 *__restrict__ slab, float (*s_d)[64], int (*s_i)[64])
+{
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const unsigned rowmask = role == 0 ? 0x007u : (role == 1 ? 0x018u : (role == 2 ? 0x060u : 0x180u));
+    Best<1> B;
+    B.init_radius(25.f);  // LO:607,758: a nearest point at 5 m or more is no correspondence
+    if (act && seed >= 0) {
+        const float4 c = cloud[seed];
+        B.consider(sqdist(p.x, p.y, p.z, c.x, c.y, c.z), make_float4(c.x, c.y, c.z, __int_as_float(seed)), 0u);
+    }
+    float px = p.x, py = p.y, pz = p.z;
+    if (!act) px = py = pz = 0.f;
+    int lvl = 0;
+    {
+        const float w0 = B.worst();
+        if (B.seeded()) {  // the seed's distance names the level (knn_query)
+            lvl = P.nlevels - 1;
+            for (int l = P.nlevels - 2; l >= 0; --l) {
+                const float g = P.lv[l].h * 0.999f - P.lv[l].margin;
+                if (g > 0.f && w0 <= g * g) lvl = l;
+            }
+        }
+    }
+    bool todo = act;
+    for (int l = 0; l < P.nlevels; ++l) {
+        if (__ballot(todo) == 0ull) break;  // the same in every wave: they hold identical records here
+        const bool a = todo && l >= lvl;
+        if (__ballot(a) == 0ull) continue;
+        const GridDesc &G = P.lv[l];
+        CellGeo C;
+        C.set(G, px, py, pz);
+        block3_level_flat(G, C, sorted, cell_start, a, px, py, pz, B, slab, rowmask);
+        s_d[role][lane] = B.d[0];
+        s_i[role][lane] = B.i[0];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = s_d[r][lane];
+            const int i = s_i[r][lane];
+            if (d < B.d[0] || (d == B.d[0] && i < B.i[0])) {
+                B.d[0] = d;
+                B.i[0] = i;
+            }
+        }
+        __syncthreads();
+        if (a && B.worst() <= C.settled_r2(G)) todo = false;
+    }
+    idx = B.i[0] == 0x7fffffff ? -1 : B.i[0];
+    sqd = B.d[0];
+}
+
 // A tile is 64 features and a workgroup its four waves: wave 0 finds every feature's nearest point of the last
 // cloud; the adjacent-ring searches need only that result and are independent of each other, so after a barrier
 // waves 1..3 run one of them each (corner: rings scan-1 | scan+1 -> min2; surf: own ring -> min2, rings scan-1 |
@@ -898,15 +957,15 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
         const float4 ps = lo_to_start(tr, pi);
         const int prev2 = act ? ci2[i] : -1;  // -1 in a sweep's first round (lo_init_kernel)
         int closest = -1, min2 = -1;
-        if (role == 0) {
+        {
             int idx;
             float sqd;
             const int prev1 = act ? ci1[i] : -1;
-            lo_nearest(CP, csorted, ccells, act, ps, idx, sqd, cl, prev1, slab);
+            lo_nearest_split(CP, csorted, ccells, act, ps, idx, sqd, cl, prev1, slab, s_rd, s_ri);
             const bool has = act && idx >= 0 && sqd < 25;
             if (has) closest = idx;
-            s_closest[lane] = closest;
-            if (!mono && has) {
+            if (role == 0) s_closest[lane] = closest;
+            if (role == 0 && !mono && has) {  // the sequential walks: one wave
             const int scan = (int)cl[closest].w;
             float d2min = 25;
             // the walks are sequential by definition (first strict minimum wins, stop at the
@@ -1005,15 +1064,15 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
         const float4 ps = lo_to_start(tr, pi);
         const int prev2 = act ? si2[i] : -1, prev3 = act ? si3[i] : -1;
         int closest = -1, min2 = -1, min3 = -1;
-        if (role == 0) {
+        {
             int idx;
             float sqd;
             const int prev1 = act ? si1[i] : -1;
-            lo_nearest(SP, ssorted, scells, act, ps, idx, sqd, sl, prev1, slab);
+            lo_nearest_split(SP, ssorted, scells, act, ps, idx, sqd, sl, prev1, slab, s_rd, s_ri);
             const bool has = act && idx >= 0 && sqd < 25;
             if (has) closest = idx;
-            s_closest[lane] = closest;
-            if (!mono && has) {
+            if (role == 0) s_closest[lane] = closest;
+            if (role == 0 && !mono && has) {  // the sequential walks: one wave
             const int scan = (int)sl[closest].w;
             float d2 = 25, d3 = 25;
             for (int j0 = closest + 1, stop = 0; j0 < fwd_s && !stop; j0 += RS) {
