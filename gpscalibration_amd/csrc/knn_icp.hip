@@ -367,16 +367,33 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
     const float4 *__restrict__ nbr, const float2 *__restrict__ pt_r2, const unsigned *__restrict__ cell_start,
     const float *__restrict__ pose32, int *__restrict__ nn_idx, float *__restrict__ nn_sqd,
     float4 *__restrict__ warm_q, unsigned *__restrict__ warm_r2, double *__restrict__ partials, int nblk, int diag,
-    int write_nn)
+    int write_nn, int uni_n, int uni_m, int uni_bpp, int uni_pair0)
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
     __shared__ double wsum[STEP_BLOCK / 64][NACC];
     __shared__ double tslab[STEP_BLOCK / 64][8][64];  // per-wave transpose slab (4 KiB / wave)
 
     const int lb = xcd_remap(blockIdx.x, nblk);
-    const int b = __builtin_amdgcn_readfirstlane(blk_pair[lb]);
-    const int first = __builtin_amdgcn_readfirstlane(blk_first[lb]);
-    const PairDesc &P = pairs[b];
+    // A batch of equal-sized scans (uni_n > 0: every source cloud uni_n points, every target cloud uni_m, stored back
+    // to back) needs no table to find a workgroup's slice: two dependent scalar loads less in front of the streams,
+    // which is a fifth of a workgroup's life in the converged state.
+    int b, first, src_n;
+    long long src_off, tgt_off;
+    if (uni_n > 0) {
+        const int bl = lb / uni_bpp;
+        b = uni_pair0 + bl;
+        first = (lb - bl * uni_bpp) * (STEP_BLOCK * QPT);
+        src_n = uni_n;
+        src_off = (long long)b * uni_n;
+        tgt_off = (long long)b * uni_m;
+    } else {
+        b = __builtin_amdgcn_readfirstlane(blk_pair[lb]);
+        first = __builtin_amdgcn_readfirstlane(blk_first[lb]);
+        src_n = pairs[b].n;
+        src_off = pairs[b].src_off;
+        tgt_off = pairs[b].tgt_off;
+    }
+    const PairDesc &P = pairs[b];  // the grid levels: read by the search only
     const float *T = pose32 + (size_t)b * 12;
     const float r00 = T[0], r01 = T[1], r02 = T[2], tx = T[3];
     const float r10 = T[4], r11 = T[5], r12 = T[6], ty = T[7];
@@ -390,17 +407,17 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
 #pragma unroll 1
     for (int q = 0; q < QPT; ++q) {
         const int i = first + q * STEP_BLOCK + (int)threadIdx.x;
-        const bool valid = i < P.n;
+        const bool valid = i < src_n;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 wq = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
         float2 wr2 = make_float2(0.f, 0.f);
         if (valid) {
             // three coalesced streams: the point, last iteration's neighbour, its radii
-            s = src4[P.src_off + i];
-            wq = warm_q[P.src_off + i];
+            s = src4[src_off + i];
+            wq = warm_q[src_off + i];
             // both radii in one word: the upper 16 bits of each float (truncation only shrinks a radius,
             // which keeps the certificates valid)
-            const unsigned pr = warm_r2[P.src_off + i];
+            const unsigned pr = warm_r2[src_off + i];
             wr2 = make_float2(__uint_as_float(pr & 0xffff0000u), __uint_as_float(pr << 16));
         }
         bool ok = valid && finite3(s.x, s.y, s.z);
@@ -417,7 +434,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
             need = !(d0 < wr2.x);  // tier 1: inside r_a, proven nearest
             if (need && d0 < wr2.y && !(diag & 4)) {
                 // tier 2: inside r_b the answer is q0 or one of its 4 listed neighbours
-                const float4 *nb = nbr + 4 * (P.tgt_off + __float_as_int(wq.w));
+                const float4 *nb = nbr + 4 * (tgt_off + __float_as_int(wq.w));
                 const float4 n0 = nb[0], n1 = nb[1], n2 = nb[2], n3 = nb[3];
                 B.consider(sqdist(px, py, pz, n0.x, n0.y, n0.z), n0, BestQ::LIST + 0);
                 B.consider(sqdist(px, py, pz, n1.x, n1.y, n1.z), n1, BestQ::LIST + 1);
@@ -439,20 +456,20 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
         if (ok && B.pos != BestQ::WARM) {
             // the neighbour changed: remember it and its radii for the next iteration
             nq = B.pos < BestQ::LIST ? sorted[B.pos]
-                                     : nbr[4 * (P.tgt_off + __float_as_int(wq.w)) + (B.pos - BestQ::LIST)];
-            warm_q[P.src_off + i] = nq;
-            const float2 r2 = pt_r2[P.tgt_off + B.index()];
-            warm_r2[P.src_off + i] = (__float_as_uint(r2.x) & 0xffff0000u) | (__float_as_uint(r2.y) >> 16);
+                                     : nbr[4 * (tgt_off + __float_as_int(wq.w)) + (B.pos - BestQ::LIST)];
+            warm_q[src_off + i] = nq;
+            const float2 r2 = pt_r2[tgt_off + B.index()];
+            warm_r2[src_off + i] = (__float_as_uint(r2.x) & 0xffff0000u) | (__float_as_uint(r2.y) >> 16);
         }
         const float bd = B.dist2();
         if (write_nn) {  // the correspondences are an output of the run's last iteration only
-            nn_idx[P.src_off + i] = ok ? B.index() : -1;
-            nn_sqd[P.src_off + i] = ok ? bd : INFINITY;
+            nn_idx[src_off + i] = ok ? B.index() : -1;
+            nn_sqd[src_off + i] = ok ? bd : INFINITY;
         }
         if (!ok) continue;
         const double dpx = px, dpy = py, dpz = pz, qx = nq.x, qy = nq.y, qz = nq.z;
         if (WEIGHTED) {
-            const double w = wsrc[P.src_off + i], w2 = w * w;
+            const double w = wsrc[src_off + i], w2 = w * w;
             acc[0] += w;
             acc[1] += w * dpx; acc[2] += w * dpy; acc[3] += w * dpz;
             acc[4] += w * qx;  acc[5] += w * qy;  acc[6] += w * qz;
@@ -942,6 +959,7 @@ struct gpscal_scan_batch {
     long long total_n = 0;
     bool weighted = false;
     int qpt = 1, nblk = 0, diag = 0;
+    int uni_n = 0, uni_m = 0, uni_bpp = 0;  // equal-sized scans stored back to back: workgroup slices by arithmetic
     int ball_r = 0;  // block radius of the ball search (0 = fine -> coarse 3x3x3 search)
     DevBuf<PairDesc> pairs;  // target descs + source fields
     std::vector<PairDesc> hpairs;
@@ -1122,6 +1140,19 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
         P.pblk_cnt = (int)bp.size() - P.pblk_off;
     }
     B->nblk = (int)bp.size();
+    // equal-sized scans stored back to back (the usual batch): the step kernel finds a workgroup's slice by arithmetic
+    {
+        bool uni = np > 0 && B->hpairs[0].n > 0;
+        for (int b = 0; b < np && uni; ++b) {
+            const PairDesc &P = B->hpairs[b];
+            uni = P.n == B->hpairs[0].n && P.m == B->hpairs[0].m && P.src_off == (long long)b * B->hpairs[0].n &&
+                  P.tgt_off == (long long)b * B->hpairs[0].m;
+        }
+        if (const char *e = getenv("GPSCAL_ICP_UNIFORM")) uni = uni && atoi(e) != 0;
+        B->uni_n = uni ? B->hpairs[0].n : 0;
+        B->uni_m = uni ? B->hpairs[0].m : 0;
+        B->uni_bpp = uni ? B->hpairs[0].pblk_cnt : 0;
+    }
     // chains: contiguous groups of pairs with (nearly) equal block counts; small batches keep one
     {
         int want = np >= 32 ? 4 : (np >= 8 ? 2 : 1);  // measured at 64 pairs x 65 536 points: 1 / 2 / 4 chains = 671 / 729 / 748 k iterations/s
@@ -1266,7 +1297,8 @@ static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st)
                        B->blk_first.p + b0, B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p, G.cell_start,   \
                        B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p,                              \
                        B->partials.p + (size_t)b0 * (B->weighted ? NACC_WEIGHTED : NACC_PLAIN), nb,                  \
-                       (B->diag & 0xff) | (B->ball_r << 8), last ? 1 : 0)
+                       (B->diag & 0xff) | (B->ball_r << 8), last ? 1 : 0, B->uni_n, B->uni_m, B->uni_bpp,            \
+                       c < 0 ? 0 : B->chain_pair[c])
     // the ball search costs the kernel a wave of occupancy: its own instantiation, chosen per batch
     const bool ball = B->ball_r > 0;
     if (B->weighted) {
