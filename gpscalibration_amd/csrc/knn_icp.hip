@@ -462,7 +462,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
             warm_r2[src_off + i] = (__float_as_uint(r2.x) & 0xffff0000u) | (__float_as_uint(r2.y) >> 16);
         }
         const float bd = B.dist2();
-        if (write_nn) {  // the correspondences are an output of the run's last iteration only
+        if (write_nn & 1) {  // the correspondences are an output of the run's last iteration only
             nn_idx[src_off + i] = ok ? B.index() : -1;
             nn_sqd[src_off + i] = ok ? bd : INFINITY;
         }
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
             acc[7] += ax * qx;  acc[8] += ax * qy;  acc[9] += ax * qz;
             acc[10] += ay * qx; acc[11] += ay * qy; acc[12] += ay * qz;
             acc[13] += az * qx; acc[14] += az * qy; acc[15] += az * qz;
-            acc[16] += sqrt((double)bd);
+            if (!(write_nn & 2)) acc[16] += sqrt((double)bd);
             acc[17] += w2;
             acc[18] += ax; acc[19] += ay; acc[20] += az;
             acc[21] += w2 * qx; acc[22] += w2 * qy; acc[23] += w2 * qz;
@@ -489,7 +489,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
             acc[7] += dpx * qx;  acc[8] += dpx * qy;  acc[9] += dpx * qz;
             acc[10] += dpy * qx; acc[11] += dpy * qy; acc[12] += dpy * qz;
             acc[13] += dpz * qx; acc[14] += dpz * qy; acc[15] += dpz * qz;
-            acc[16] += sqrt((double)bd);
+            // the mean correspondence distance is an output only when the caller asks for the error history
+            if (!(write_nn & 2)) acc[16] += sqrt((double)bd);
         }
     }
     // Block reduction in fixed order.  Each wave transposes 8 accumulators at a time
@@ -976,7 +977,7 @@ struct gpscal_scan_batch {
     // captured graphs by iteration count (callers that alternate between two counts keep both)
     static constexpr int NGRAPH = 4;
     hipGraphExec_t graphs[NGRAPH] = {};
-    int graph_iters[NGRAPH] = {};
+    int graph_iters[NGRAPH] = {};  // key: 2 * iterations + (error history wanted)
     unsigned graph_used[NGRAPH] = {}, graph_clock = 0;
     void drop_graphs()
     {
@@ -1286,7 +1287,7 @@ extern "C" int gpscal_debug_stats(unsigned long long *out, int n)
 // step -> solve -> step ...: while one group's solve kernel (one wave per pair, ~9 us of dependent float64
 // arithmetic) runs, the other groups' step kernels keep the chip busy.  Chain c = pairs [chain_pair[c],
 // chain_pair[c+1]) = blocks [chain_blk[c], chain_blk[c+1]); partial-sum slots stay global.
-static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st)
+static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st, bool want_err = true)
 {
     GridSet &G = *B->tgt;
     // c < 0: the whole batch in one launch (profiling mode: the launch the roofline is quoted for)
@@ -1297,7 +1298,8 @@ static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st)
                        B->blk_first.p + b0, B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p, G.cell_start,   \
                        B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p,                              \
                        B->partials.p + (size_t)b0 * (B->weighted ? NACC_WEIGHTED : NACC_PLAIN), nb,                  \
-                       (B->diag & 0xff) | (B->ball_r << 8), last ? 1 : 0, B->uni_n, B->uni_m, B->uni_bpp,            \
+                       (B->diag & 0xff) | (B->ball_r << 8), (last ? 1 : 0) | (want_err ? 0 : 2), B->uni_n, B->uni_m,   \
+                       B->uni_bpp,                                                                                  \
                        c < 0 ? 0 : B->chain_pair[c])
     // the ball search costs the kernel a wave of occupancy: its own instantiation, chosen per batch
     const bool ball = B->ball_r > 0;
@@ -1328,6 +1330,7 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
     gpscal_ctx *ctx = B->ctx;
     GPSCAL_HIP(ctx, hipSetDevice(ctx->device));
     const int np = B->npairs;
+    const bool want_err = mean_err != nullptr;  // without it the step kernel skips the distance sum (a float64 sqrt per query)
     if (iters > B->err_cap) {
         B->drop_graphs();  // they hold the old error-history pointer
         GPSCAL_HIP(ctx, B->err_hist.alloc((size_t)np * iters));
@@ -1342,7 +1345,7 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
             hipLaunchKernelGGL(stat_set_iter_kernel, dim3(1), dim3(1), 0, ctx->stream, std::min(it, STAT_ITERS - 1));
 #endif
             GPSCAL_HIP(ctx, hipEventRecord(ev[2 * it], ctx->stream));
-            launch_step(B, it == iters - 1, -1, ctx->stream);
+            launch_step(B, it == iters - 1, -1, ctx->stream, want_err);
             GPSCAL_HIP(ctx, hipEventRecord(ev[2 * it + 1], ctx->stream));
             launch_solve(B, it, -1, ctx->stream);
         }
@@ -1351,9 +1354,10 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
         for (int it = 0; it < iters; ++it) GPSCAL_HIP(ctx, hipEventElapsedTime(&step_ms[it], ev[2 * it], ev[2 * it + 1]));
         for (auto &e : ev) (void)hipEventDestroy(e);
     } else if (iters > 0) {
+        const int gkey = 2 * iters + (want_err ? 1 : 0);  // a graph per (iteration count, error history wanted)
         int slot = -1;
         for (int k = 0; k < gpscal_scan_batch::NGRAPH; ++k)
-            if (B->graphs[k] && B->graph_iters[k] == iters) slot = k;
+            if (B->graphs[k] && B->graph_iters[k] == gkey) slot = k;
         if (slot < 0) {
             slot = 0;  // an empty slot, else the least recently used one
             for (int k = 0; k < gpscal_scan_batch::NGRAPH; ++k) {
@@ -1377,7 +1381,7 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
             for (int it = 0; it < iters; ++it)
                 for (int c = 0; c < B->nchains; ++c) {
                     hipStream_t st = c == 0 ? ctx->stream : B->chain_stream[c];
-                    launch_step(B, it == iters - 1, c, st);
+                    launch_step(B, it == iters - 1, c, st, want_err);
                     launch_solve(B, it, c, st);
                 }
             for (int c = 1; c < B->nchains; ++c) {
@@ -1387,7 +1391,7 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
             GPSCAL_HIP(ctx, hipStreamEndCapture(ctx->stream, &g));
             GPSCAL_HIP(ctx, hipGraphInstantiate(&B->graphs[slot], g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
-            B->graph_iters[slot] = iters;
+            B->graph_iters[slot] = gkey;
         }
         B->graph_used[slot] = ++B->graph_clock;
         GPSCAL_HIP(ctx, hipGraphLaunch(B->graphs[slot], ctx->stream));
