@@ -86,6 +86,115 @@ __device__ __forceinline__ void mark_neighbours(unsigned *picked, unsigned *gap,
     __builtin_amdgcn_wave_barrier();
 }
 
+// One wave's greedy pick of one sorted sector (SR:578-657): K[0, cnt) = (curvature bits, point index), ascending.
+// cnt3 = {sharp, less sharp, flat} points written so far to o_sharp / o_lsharp / o_flat (LDS counters).
+__device__ __forceinline__ void sr_pick_sector(const unsigned long long *K, int cnt, unsigned *picked, unsigned *gap,
+                                               unsigned *labpos, const float4 *__restrict__ cloud,
+                                               float4 *__restrict__ o_sharp, float4 *__restrict__ o_lsharp,
+                                               float4 *__restrict__ o_flat, int *cnt3, int cs, int lane)
+{
+    int n_sharp = cnt3[0], n_lsharp = cnt3[1], n_flat = cnt3[2];
+    // corners: from the largest curvature down (SR:578-619)
+    int largest = 0;
+    bool done = false;
+    for (int top = cnt - 1; top >= 0 && !done; top -= 64) {
+        const int k = top - lane;
+        const bool valid = k >= 0;
+        const unsigned long long key = valid ? K[k] : 0ull;
+        const int ind = (int)(unsigned)key;
+        const bool cand = valid && (double)__uint_as_float((unsigned)(key >> 32)) > 0.1;
+        while (true) {
+            const unsigned long long m = __ballot(cand && !get_bit(picked, ind));
+            if (!m) break;
+            const int f = __ffsll((long long)m) - 1;
+            const int indf = __shfl(ind, f);
+            ++largest;
+            if (largest > 20) {
+                done = true;
+                break;
+            }
+            if (lane == 0) {
+                const float4 pt = cloud[indf];
+                if (largest <= 16) o_sharp[n_sharp] = pt;
+                o_lsharp[n_lsharp] = pt;
+                set_bit(labpos, indf);
+            }
+            if (largest <= 16) ++n_sharp;
+            ++n_lsharp;
+            mark_neighbours(picked, gap, indf, cs, lane);
+        }
+    }
+    // flat points: from the smallest curvature up (SR:621-657)
+    int smallest = 0;
+    done = false;
+    for (int bot = 0; bot < cnt && !done; bot += 64) {
+        const int k = bot + lane;
+        const bool valid = k < cnt;
+        const unsigned long long key = valid ? K[k] : 0ull;
+        const int ind = (int)(unsigned)key;
+        const bool cand = valid && (double)__uint_as_float((unsigned)(key >> 32)) < 0.1;
+        while (true) {
+            const unsigned long long m = __ballot(cand && !get_bit(picked, ind));
+            if (!m) break;
+            const int f = __ffsll((long long)m) - 1;
+            const int indf = __shfl(ind, f);
+            if (lane == 0) o_flat[n_flat] = cloud[indf];
+            ++n_flat;
+            ++smallest;
+            if (smallest >= 32) {
+                done = true;
+                break;
+            }
+            mark_neighbours(picked, gap, indf, cs, lane);
+        }
+    }
+    if (lane == 0) {
+        cnt3[0] = n_sharp;
+        cnt3[1] = n_lsharp;
+        cnt3[2] = n_flat;
+    }
+
+}
+
+// Stable ascending sort by curvature of one sector (the insertion sort of SR:567-575) by ONE wave, in that wave's own
+// key buffers: sid[sp, sp + cnt) is rewritten in sorted order and K[k] = (curvature bits, point index).
+__device__ __forceinline__ void sr_wave_sort_sector(unsigned long long *K, int *OLD, const float *__restrict__ cv,
+                                                    int *__restrict__ sid, int sp, int cnt, int lane)
+{
+    const int np2 = next_pow2(cnt);
+    for (int k = lane; k < np2; k += 64) {
+        unsigned long long key = ~0ull;
+        if (k < cnt) {
+            const int ind = sid[sp + k];
+            OLD[k] = ind;
+            key = ((unsigned long long)__float_as_uint(cv[ind]) << 32) | (unsigned)k;
+        }
+        K[k] = key;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (np2 >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const bool up = (i & k) == 0;
+                const unsigned long long a = K[i], b = K[p];
+                if ((a > b) == up) {
+                    K[i] = b;
+                    K[p] = a;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    for (int k = lane; k < cnt; k += 64) {
+        const unsigned long long key = K[k];
+        const int ind = OLD[(unsigned)key];
+        K[k] = (key & 0xffffffff00000000ull) | (unsigned)ind;
+        sid[sp + k] = ind;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(SBLOCK) void scan_registration_kernel(
     const SrDesc *__restrict__ descs, const float *__restrict__ xyz, float4 *__restrict__ full,
     float4 *__restrict__ sharp, float4 *__restrict__ less_sharp, float4 *__restrict__ flat,
@@ -321,113 +430,90 @@ __global__ __launch_bounds__(SBLOCK) void scan_registration_kernel(
     }
     __syncthreads();
 
-    // ---- picking, ring by ring and sector by sector (SR:558-674)
-    for (int ring = 0; ring < N_RINGS; ++ring) {
-        if (threadIdx.x == 0) {
-            s_nl = 0;
-            if (ring_counts) {  // less-sharp / less-flat points emitted by this ring index so far
-                ring_counts[32 * b + ring] = -S.counts[2];
-                ring_counts[32 * b + 16 + ring] = -S.counts[4];
+    // ---- picking (SR:558-674).  The 96 (ring, sector) rounds are order dependent only inside a ring (marks spill
+    // +-5 points across sector borders, never across a ring's own +-5 margin), and a round is one wave's work (~50
+    // sequential ballots): when every sector fits a wave's share of the LDS key buffer, the eight waves pick two
+    // rings each side by side -- into the ring's own stretch of the output arrays, which are sized for exactly that
+    // (16 x 96 sharp, 16 x 120 less sharp, 16 x 192 flat) -- and the lists are closed up in ring order afterwards.
+    __shared__ int s_par;
+    __shared__ int r_cnt[N_RINGS][3];
+    __shared__ int r_pre[3][N_RINGS + 1];
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        for (int ring = 0; ring < N_RINGS; ++ring)
+            for (int j = 0; j < 6; ++j) {
+                const int sp = (S.scan_start[ring] * (6 - j) + S.scan_end[ring] * j) / 6;
+                const int ep = (S.scan_start[ring] * (5 - j) + S.scan_end[ring] * (j + 1)) / 6 - 1;
+                if (ep - sp + 1 > LDS_KEYS / SWAVES) ok = 0;
             }
+        s_par = ok;
+    }
+    if (threadIdx.x < N_RINGS * 3) r_cnt[threadIdx.x / 3][threadIdx.x % 3] = 0;
+    __syncthreads();
+    if (s_par) {
+        unsigned long long *Kw = lds_keys + wave * (LDS_KEYS / SWAVES);
+        int *Ow = lds_old + wave * (LDS_KEYS / SWAVES);
+        for (int ring = wave; ring < N_RINGS; ring += SWAVES)
+            for (int j = 0; j < 6; ++j) {
+                const int sp = (S.scan_start[ring] * (6 - j) + S.scan_end[ring] * j) / 6;
+                const int ep = (S.scan_start[ring] * (5 - j) + S.scan_end[ring] * (j + 1)) / 6 - 1;
+                const int cnt = ep - sp + 1;
+                if (cnt <= 0) continue;
+                sr_wave_sort_sector(Kw, Ow, cv, sid, sp, cnt, lane);
+                sr_pick_sector(Kw, cnt, picked, gap, labpos, cloud, o_sharp + ring * 96, o_lsharp + ring * 120,
+                               o_flat + ring * 192, r_cnt[ring], cs, lane);
+            }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            int acc = 0;
+            for (int r = 0; r < N_RINGS; ++r) {
+                r_pre[threadIdx.x][r] = acc;
+                acc += r_cnt[r][threadIdx.x];
+            }
+            r_pre[threadIdx.x][N_RINGS] = acc;
         }
         __syncthreads();
-        for (int j = 0; j < 6; ++j) {
-            const int sp = (S.scan_start[ring] * (6 - j) + S.scan_end[ring] * j) / 6;
-            const int ep = (S.scan_start[ring] * (5 - j) + S.scan_end[ring] * (j + 1)) / 6 - 1;
-            const int cnt = ep - sp + 1;
-            if (cnt <= 0) continue;  // uniform
-            const int np2 = next_pow2(cnt);
-            const bool in_lds = np2 <= LDS_KEYS;
-            unsigned long long *K = in_lds ? lds_keys : gk;
-            int *OLD = in_lds ? lds_old : go;
-            if (!in_lds && np2 > D.key_cap) {
-                if (threadIdx.x == 0) S.overflow = 1;
-                continue;
-            }
-            // stable ascending sort by curvature = the insertion sort of SR:567-575
-            for (int k = threadIdx.x; k < np2; k += SBLOCK) {
-                unsigned long long key = ~0ull;
-                if (k < cnt) {
-                    const int ind = sid[sp + k];
-                    OLD[k] = ind;
-                    key = ((unsigned long long)__float_as_uint(cv[ind]) << 32) | (unsigned)k;
-                }
-                K[k] = key;
-            }
-            __syncthreads();
-            block_bitonic_sort(K, np2);
-            for (int k = threadIdx.x; k < cnt; k += SBLOCK) {
-                const unsigned long long key = K[k];
-                const int ind = OLD[(unsigned)key];
-                K[k] = (key & 0xffffffff00000000ull) | (unsigned)ind;
-                sid[sp + k] = ind;
-            }
-            __syncthreads();
-            if (wave == 0) {
-                int n_sharp = S.counts[1], n_lsharp = S.counts[2], n_flat = S.counts[3];
-                // corners: from the largest curvature down (SR:578-619)
-                int largest = 0;
-                bool done = false;
-                for (int top = cnt - 1; top >= 0 && !done; top -= 64) {
-                    const int k = top - lane;
-                    const bool valid = k >= 0;
-                    const unsigned long long key = valid ? K[k] : 0ull;
-                    const int ind = (int)(unsigned)key;
-                    const bool cand = valid && (double)__uint_as_float((unsigned)(key >> 32)) > 0.1;
-                    while (true) {
-                        const unsigned long long m = __ballot(cand && !get_bit(picked, ind));
-                        if (!m) break;
-                        const int f = __ffsll((long long)m) - 1;
-                        const int indf = __shfl(ind, f);
-                        ++largest;
-                        if (largest > 20) {
-                            done = true;
-                            break;
-                        }
-                        if (lane == 0) {
-                            const float4 pt = cloud[indf];
-                            if (largest <= 16) o_sharp[n_sharp] = pt;
-                            o_lsharp[n_lsharp] = pt;
-                            set_bit(labpos, indf);
-                        }
-                        if (largest <= 16) ++n_sharp;
-                        ++n_lsharp;
-                        mark_neighbours(picked, gap, indf, cs, lane);
+        {  // close the three lists up: every element is read before any is written
+            float4 v[3][6];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float4 *base = t == 0 ? o_sharp : (t == 1 ? o_lsharp : o_flat);
+                const int cap = t == 0 ? 96 : (t == 1 ? 120 : 192);
+                const int tot = r_pre[t][N_RINGS];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int e = threadIdx.x + u * SBLOCK;
+                    v[t][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < tot) {
+                        int r = 0;
+                        while (r + 1 < N_RINGS && r_pre[t][r + 1] <= e) ++r;
+                        v[t][u] = base[r * cap + (e - r_pre[t][r])];
                     }
                 }
-                // flat points: from the smallest curvature up (SR:621-657)
-                int smallest = 0;
-                done = false;
-                for (int bot = 0; bot < cnt && !done; bot += 64) {
-                    const int k = bot + lane;
-                    const bool valid = k < cnt;
-                    const unsigned long long key = valid ? K[k] : 0ull;
-                    const int ind = (int)(unsigned)key;
-                    const bool cand = valid && (double)__uint_as_float((unsigned)(key >> 32)) < 0.1;
-                    while (true) {
-                        const unsigned long long m = __ballot(cand && !get_bit(picked, ind));
-                        if (!m) break;
-                        const int f = __ffsll((long long)m) - 1;
-                        const int indf = __shfl(ind, f);
-                        if (lane == 0) o_flat[n_flat] = cloud[indf];
-                        ++n_flat;
-                        ++smallest;
-                        if (smallest >= 32) {
-                            done = true;
-                            break;
-                        }
-                        mark_neighbours(picked, gap, indf, cs, lane);
-                    }
-                }
-                if (lane == 0) {
-                    S.counts[1] = n_sharp;
-                    S.counts[2] = n_lsharp;
-                    S.counts[3] = n_flat;
-                }
             }
             __syncthreads();
-            // everything of the sector that is not a corner (SR:659-663)
-            int nl = s_nl;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float4 *base = t == 0 ? o_sharp : (t == 1 ? o_lsharp : o_flat);
+                const int tot = r_pre[t][N_RINGS];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int e = threadIdx.x + u * SBLOCK;
+                    if (e < tot) base[e] = v[t][u];
+                }
+            }
+        }
+        if (threadIdx.x == 0) {
+            S.counts[1] = r_pre[0][N_RINGS];
+            S.counts[2] = r_pre[1][N_RINGS];
+            S.counts[3] = r_pre[2][N_RINGS];
+        }
+        __syncthreads();
+        // the less-flat points ring by ring: everything that is not a corner (SR:659-663), then VoxelGrid 0.2
+        for (int ring = 0; ring < N_RINGS; ++ring) {
+            const int sp = S.scan_start[ring], ep = S.scan_end[ring] - 1;  // the six sectors are contiguous
+            int nl = 0;
+            const int before = S.counts[4];
             __syncthreads();
             for (int k0 = sp; k0 <= ep; k0 += SBLOCK) {
                 const int k = k0 + threadIdx.x;
@@ -437,16 +523,81 @@ __global__ __launch_bounds__(SBLOCK) void scan_registration_kernel(
                 if (keep) lf[nl + r] = cloud[k];
                 nl += tot;
             }
-            if (threadIdx.x == 0) s_nl = nl;
             __syncthreads();
+            block_voxel_grid(S, lf, nl, 0.2f, o_lflat, D.lf_cap, &S.counts[4], lds_keys, gk, D.key_cap);  // SR:667-673
+            __syncthreads();
+            if (threadIdx.x == 0 && ring_counts) {
+                ring_counts[32 * b + ring] = r_cnt[ring][1];
+                ring_counts[32 * b + 16 + ring] = S.counts[4] - before;
+            }
         }
-        const int nl = s_nl;
-        __syncthreads();
-        block_voxel_grid(S, lf, nl, 0.2f, o_lflat, D.lf_cap, &S.counts[4], lds_keys, gk, D.key_cap);  // SR:667-673
-        __syncthreads();
-        if (threadIdx.x == 0 && ring_counts) {
-            ring_counts[32 * b + ring] += S.counts[2];
-            ring_counts[32 * b + 16 + ring] += S.counts[4];
+    } else {
+        // ---- picking, ring by ring and sector by sector (SR:558-674)
+        for (int ring = 0; ring < N_RINGS; ++ring) {
+            if (threadIdx.x == 0) {
+                s_nl = 0;
+                if (ring_counts) {  // less-sharp / less-flat points emitted by this ring index so far
+                    ring_counts[32 * b + ring] = -S.counts[2];
+                    ring_counts[32 * b + 16 + ring] = -S.counts[4];
+                }
+            }
+            __syncthreads();
+            for (int j = 0; j < 6; ++j) {
+                const int sp = (S.scan_start[ring] * (6 - j) + S.scan_end[ring] * j) / 6;
+                const int ep = (S.scan_start[ring] * (5 - j) + S.scan_end[ring] * (j + 1)) / 6 - 1;
+                const int cnt = ep - sp + 1;
+                if (cnt <= 0) continue;  // uniform
+                const int np2 = next_pow2(cnt);
+                const bool in_lds = np2 <= LDS_KEYS;
+                unsigned long long *K = in_lds ? lds_keys : gk;
+                int *OLD = in_lds ? lds_old : go;
+                if (!in_lds && np2 > D.key_cap) {
+                    if (threadIdx.x == 0) S.overflow = 1;
+                    continue;
+                }
+                // stable ascending sort by curvature = the insertion sort of SR:567-575
+                for (int k = threadIdx.x; k < np2; k += SBLOCK) {
+                    unsigned long long key = ~0ull;
+                    if (k < cnt) {
+                        const int ind = sid[sp + k];
+                        OLD[k] = ind;
+                        key = ((unsigned long long)__float_as_uint(cv[ind]) << 32) | (unsigned)k;
+                    }
+                    K[k] = key;
+                }
+                __syncthreads();
+                block_bitonic_sort(K, np2);
+                for (int k = threadIdx.x; k < cnt; k += SBLOCK) {
+                    const unsigned long long key = K[k];
+                    const int ind = OLD[(unsigned)key];
+                    K[k] = (key & 0xffffffff00000000ull) | (unsigned)ind;
+                    sid[sp + k] = ind;
+                }
+                __syncthreads();
+                if (wave == 0) sr_pick_sector(K, cnt, picked, gap, labpos, cloud, o_sharp, o_lsharp, o_flat, &S.counts[1], cs, lane);
+                __syncthreads();
+                // everything of the sector that is not a corner (SR:659-663)
+                int nl = s_nl;
+                __syncthreads();
+                for (int k0 = sp; k0 <= ep; k0 += SBLOCK) {
+                    const int k = k0 + threadIdx.x;
+                    const bool keep = k <= ep && !get_bit(labpos, k);
+                    int tot;
+                    const int r = block_rank(S, keep, tot);
+                    if (keep) lf[nl + r] = cloud[k];
+                    nl += tot;
+                }
+                if (threadIdx.x == 0) s_nl = nl;
+                __syncthreads();
+            }
+            const int nl = s_nl;
+            __syncthreads();
+            block_voxel_grid(S, lf, nl, 0.2f, o_lflat, D.lf_cap, &S.counts[4], lds_keys, gk, D.key_cap);  // SR:667-673
+            __syncthreads();
+            if (threadIdx.x == 0 && ring_counts) {
+                ring_counts[32 * b + ring] += S.counts[2];
+                ring_counts[32 * b + 16 + ring] += S.counts[4];
+            }
         }
     }
     if (threadIdx.x == 0) {
