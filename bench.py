@@ -211,7 +211,7 @@ def loam_chain_bench(ctx, nseg=6, nsweeps=30, n_az=1800, cpu=True):
         sw, st, _ = synth.drive(W, nsweeps, seed=100 + sgm, n_az=n_az, start=(20.0 * sgm, 0.3 * (sgm % 8)))
         segs.append(sw)
         stamps.append(st)
-    ctx.loam_run([segs[0][:4]], [stamps[0][:4]])  # warm-up
+    ctx.loam_run(segs, stamps)  # warm-up with the run's own shape: code objects and the block cache (the chain's pools)
     t0 = time.perf_counter()
     got = ctx.loam_run(segs, stamps)
     dt = time.perf_counter() - t0
