@@ -1105,7 +1105,7 @@ struct LoamPipe {
 
     // laserMapping's part of a step, on ctx->stream (LM:420-1079, every second published sweep), after step_tm of
     // the same step.  Host outputs (may be null): lo / lm poses, iterations.  Synchronises the stream.
-    int step_mapping(const StepSlot &L, float *lo, float *lm, int *iters)
+    int step_mapping(const StepSlot &L, float *lo, float *lm, int *iters, float *tm = nullptr, double *track = nullptr)
     {
         auto t0 = clk::now();
         hipStream_t q = ctx->stream;
@@ -1170,7 +1170,12 @@ struct LoamPipe {
         }
         t_add(4, t0);
         t0 = clk::now();
-        if (lm || iters)
+        // (tm / track given: transformMaintenance's outputs of this step come back with the same read-back --
+        // one host wait per step when nothing on the host needs them earlier)
+        const bool with_tm = tm || track;
+        if (with_tm)
+            GPSCAL_HIP(ctx, hipMemcpyAsync(h_step_out.data(), d_step_out.p, step_out_bytes, hipMemcpyDeviceToHost, q));
+        else if (lm || iters)
             GPSCAL_HIP(ctx, hipMemcpyAsync(h_step_out.data() + tm_out_bytes, d_step_out.p + tm_out_bytes,
                                            step_out_bytes - tm_out_bytes, hipMemcpyDeviceToHost, q));
         if (lo) GPSCAL_HIP(ctx, hipMemcpyAsync(lo, d_step_lo[buf].p, sizeof(float) * 6 * nseg, hipMemcpyDeviceToHost, q));
@@ -1179,6 +1184,8 @@ struct LoamPipe {
             const char *h = h_step_out.data() + tm_out_bytes;
             if (lm) memcpy(lm, h, sizeof(float) * 6 * nseg);
             if (iters) memcpy(iters, h + sizeof(float) * 6 * nseg, sizeof(int) * nseg);
+            if (track) memcpy(track, h_step_out.data(), sizeof(double) * 4 * nseg);
+            if (tm) memcpy(tm, h_step_out.data() + sizeof(double) * 4 * nseg, sizeof(float) * 6 * nseg);
         }
         t_add(5, t0);
         return GPSCAL_OK;
@@ -1187,9 +1194,9 @@ struct LoamPipe {
     // Mapping half of a step: both parts.
     int step_map(const StepSlot &L, float *lo, float *lm, float *tm, double *track, int *iters)
     {
-        int rc = step_tm(L, tm, track);
+        int rc = step_tm(L, nullptr, nullptr);  // enqueued only: its outputs come back with the mapping part's
         if (rc) return rc;
-        return step_mapping(L, lo, lm, iters);
+        return step_mapping(L, lo, lm, iters, tm, track);
     }
 
     // One sweep per stream (sweep_idx[s] < 0: the stream idles), both halves one after the other on the
