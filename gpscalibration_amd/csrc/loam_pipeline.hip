@@ -497,11 +497,16 @@ __global__ __launch_bounds__(SBLOCK) void lm_insert_kernel(SegState *__restrict_
                                                            const int *__restrict__ sizes, const float *__restrict__ tr_out,
                                                            const int *__restrict__ iters, const int *__restrict__ rows,
                                                            float *__restrict__ lm_aft_out, int *__restrict__ lm_iters_out,
-                                                           int *__restrict__ status)
+                                                           int *__restrict__ status, int counting)
 {
     extern __shared__ unsigned long long dyn_lds[];
     __shared__ float tTobe[6];
     __shared__ int s_voff[MAXVALID + 1];
+    // counting sort of the new points by cube (see below)
+    constexpr int DMAX = 64;
+    __shared__ unsigned s_seen[(LNUM + 31) / 32];
+    __shared__ unsigned char s_slot[LNUM];
+    __shared__ int s_cube[DMAX], s_nd, s_hist[SWAVES][DMAX], s_off[SWAVES][DMAX];
     const int s = blockIdx.x;
     SegState &G = st[s];
     if (!G.active) return;
@@ -549,6 +554,88 @@ __global__ __launch_bounds__(SBLOCK) void lm_insert_kernel(SegState *__restrict_
             ns[c] = 0;
             nc[c] = 0;
         }
+        // The new points go into their cubes in stack order: a stable sort by cube id.  A sweep reaches only a
+        // handful of the 50 m cubes, so instead of a bitonic sort of (cube, position) keys by this one workgroup
+        // (27k keys through HBM: ~330 us) the points are COUNTED: distinct cubes -> slots (at most DMAX, else the
+        // sort below), every wave takes a contiguous eighth of the stack, per-(wave, slot) counts give each wave its
+        // offsets, and the wave places its points tile by tile with ballot ranks -- the same order, bit for bit.
+        bool counted = false;
+        if (counting && n > LDS_KEYS && n <= dims.key_cap[type]) {
+            int *cubes = reinterpret_cast<int *>(B.keys[type] + (long long)s * dims.key_cap[type]);
+            for (int w = threadIdx.x; w < (LNUM + 31) / 32; w += SBLOCK) s_seen[w] = 0u;
+            for (int k = threadIdx.x; k < SWAVES * DMAX; k += SBLOCK) (&s_hist[0][0])[k] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += SBLOCK) {
+                const float4 q = dev_to_map(g, stack[i]);
+                s2[i] = q;
+                const int a = dev_cube_of(q.x, G.cenW), b = dev_cube_of(q.y, G.cenH), c = dev_cube_of(q.z, G.cenD);
+                int cube = -1;
+                if (a >= 0 && a < LW && b >= 0 && b < LH && c >= 0 && c < LDp) {
+                    cube = a + LW * b + LW * LH * c;
+                    atomicOr(&s_seen[cube >> 5], 1u << (cube & 31));
+                }
+                cubes[i] = cube;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {  // the cubes that occur, in increasing order
+                int nd = 0;
+                for (int w = 0; w < (LNUM + 31) / 32; ++w) {
+                    unsigned m = s_seen[w];
+                    while (m) {
+                        const int bit = __ffs(m) - 1;
+                        m &= m - 1;
+                        if (nd < DMAX) {
+                            s_cube[nd] = 32 * w + bit;
+                            s_slot[32 * w + bit] = (unsigned char)nd;
+                        }
+                        ++nd;
+                    }
+                }
+                s_nd = nd;
+            }
+            __syncthreads();
+            if (s_nd <= DMAX) {
+                counted = true;
+                const int nd = s_nd;
+                const int chunk = (n + SWAVES - 1) / SWAVES, c0 = wave * chunk, c1 = min(n, c0 + chunk);
+                for (int i = c0 + lane; i < c1; i += 64) {
+                    const int cube = cubes[i];
+                    if (cube >= 0) atomicAdd(&s_hist[wave][s_slot[cube]], 1);
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    int acc = 0;
+                    for (int d = 0; d < nd; ++d) {
+                        ns[s_cube[d]] = acc;
+                        for (int w = 0; w < SWAVES; ++w) {
+                            s_off[w][d] = acc;
+                            acc += s_hist[w][d];
+                        }
+                        nc[s_cube[d]] = acc - ns[s_cube[d]];
+                    }
+                }
+                __syncthreads();
+                for (int i0 = c0; i0 < c1; i0 += 64) {  // wave-uniform
+                    const int i = i0 + lane;
+                    int slot = -1;
+                    if (i < c1) {
+                        const int cube = cubes[i];
+                        if (cube >= 0) slot = s_slot[cube];
+                    }
+                    unsigned long long todo = __ballot(slot >= 0);
+                    while (todo) {
+                        const int d = __shfl(slot, (int)__builtin_ctzll(todo));
+                        const unsigned long long m = __ballot(slot == d);
+                        todo &= ~m;
+                        if (slot == d) newq[s_off[wave][d] + __popcll(m & ((1ull << lane) - 1ull))] = s2[i];
+                        if (lane == 0) s_off[wave][d] += __popcll(m);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (!counted) {
         for (int i = threadIdx.x; i < np2; i += SBLOCK) {
             unsigned long long key = ~0ull;
             if (i < n) {
@@ -577,6 +664,7 @@ __global__ __launch_bounds__(SBLOCK) void lm_insert_kernel(SegState *__restrict_
             const bool last = j + 1 >= n || K[j + 1] == ~0ull || (unsigned)(K[j + 1] >> 32) != cube;
             if (last) nc[cube] = j + 1 - ns[cube];
         }
+        }  // !counted
         __syncthreads();
         // inputs of the voxel filters of the valid cubes: old points, then the new ones
         const int *ts = B.tab_start[type][cur] + (long long)s * LNUM, *tc = B.tab_cnt[type][cur] + (long long)s * LNUM;
@@ -743,6 +831,13 @@ namespace {
 #ifndef GPSCAL_LOAM_RING
 #define GPSCAL_LOAM_RING 4  // measured at 6 segments: 3 / 4 / 6 slots = 2 170 / 2 230 / 2 235 sweeps/s
 #endif
+
+// GPSCAL_LM_COUNTING=0: lm_insert_kernel sorts the new points by cube with the bitonic sort again
+inline bool lm_counting()
+{
+    const char *e = getenv("GPSCAL_LM_COUNTING");
+    return e ? atoi(e) != 0 : true;
+}
 
 // GPSCAL_LOAM_PIPELINE=0: gpscal_loam_run_batched runs the two halves of a step one after the other again
 inline bool loam_pipelined()
@@ -1162,7 +1257,7 @@ struct LoamPipe {
             t_add(3, t0);
             t0 = clk::now();
             hipLaunchKernelGGL(lm_insert_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, S, dims, B, d_sizes.p, d_mtr2.p,
-                               d_iters.p, d_rows.p, d_step_lm, d_step_it, d_status.p);
+                               d_iters.p, d_rows.p, d_step_lm, d_step_it, d_status.p, lm_counting() ? 1 : 0);
             hipLaunchKernelGGL(lm_filter_kernel, dim3(MAXVALID, nseg * 2), dim3(SBLOCK), lds_keys, q, S, dims, B, d_status.p);
             hipLaunchKernelGGL(lm_rebuild_kernel, dim3(nseg * 2), dim3(SBLOCK), 0, q, S, dims, B, d_status.p);
             hipLaunchKernelGGL(lm_flip_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, nseg);

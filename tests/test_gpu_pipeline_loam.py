@@ -63,6 +63,15 @@ def test_loam_run_two_segments_match_oracle(ctx):
         del os.environ["GPSCAL_LOAM_PIPELINE"]
     for g, h in zip(got, lock_step):
         assert all(np.array_equal(g[k], h[k], equal_nan=True) for k in g)
+    # the new points of a mapping cycle are counted into their cubes (lm_insert_kernel); the bitonic sort of
+    # (cube, position) keys it replaces gives the same map, bit for bit
+    os.environ["GPSCAL_LM_COUNTING"] = "0"
+    try:
+        sorted_insert = ctx.loam_run([sw_a, sw_b], [st_a, st_b])
+    finally:
+        del os.environ["GPSCAL_LM_COUNTING"]
+    for g, h in zip(got, sorted_insert):
+        assert all(np.array_equal(g[k], h[k], equal_nan=True) for k in g)
     again = ctx.loam_run([sw_a, sw_b], [st_a, st_b])  # and is reproducible from run to run
     for g, h in zip(got, again):
         assert all(np.array_equal(g[k], h[k], equal_nan=True) for k in g)
