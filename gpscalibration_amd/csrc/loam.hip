@@ -515,15 +515,38 @@ __global__ void lm_init_kernel(const MapDesc *__restrict__ sweeps, int nsweeps, 
 }
 
 // block partial of the 28 sums -> partial[(b * tiles_max + tile) * LSUMS + k]
+// The 28 sums of a wave, lanes folded in a fixed order, written to out[0..LSUMS) by the lanes that end up holding
+// them.  Eight accumulators at a time go through the wave's private LDS slab (8 x 64 doubles): lane (k, seg) adds
+// eight consecutive lanes' copies of value k (4 x ds_read_b128), three DPP steps fold the eight segments -- ~130
+// instructions against ~1 100 for 28 full DPP wave reductions (12 dpp moves, 6 adds, 2 readlanes and their hazard
+// nops each), which were 45 % of an iteration of lo_iter_kernel.
+__device__ __forceinline__ void wave_sums28(const double (&sum)[LSUMS], double *__restrict__ slab, double *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int g0 = 0; g0 < LSUMS; g0 += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (g0 + k < LSUMS) slab[k * 64 + lane] = sum[g0 + k];
+        __builtin_amdgcn_wave_barrier();
+        const int k = lane >> 3, seg = lane & 7;
+        const double2 *row = reinterpret_cast<const double2 *>(slab + k * 64 + seg * 8);
+        const double2 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+        double v = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
+        v = dpp_add_f64<0x111, 0xF>(v);  // row_shr:1
+        v = dpp_add_f64<0x112, 0xF>(v);  // row_shr:2
+        v = dpp_add_f64<0x114, 0xF>(v);  // row_shr:4 -> lane 8k+7 holds value k
+        if (seg == 7 && g0 + k < LSUMS) out[g0 + k] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __device__ __forceinline__ void tile_partial(double (&sum)[LSUMS], double *__restrict__ out)
 {
     __shared__ double red[PT_WAVES][LSUMS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < LSUMS; ++k) {
-        const double v = wave_sum(sum[k]);
-        if (lane == 0) red[wave][k] = v;
-    }
+    __shared__ double slab[PT_WAVES][8 * 64];
+    const int wave = threadIdx.x >> 6;
+    wave_sums28(sum, &slab[wave][0], &red[wave][0]);
     __syncthreads();
     if (threadIdx.x < LSUMS) {
         double v = 0;
@@ -1191,11 +1214,12 @@ __global__ __launch_bounds__(LBLOCK) void lo_iter_kernel(
     if (S.done) return;
     __shared__ float tr[6];
     __shared__ double red[LWAVES][LSUMS];
+    __shared__ double s_slab[LWAVES][8 * 64];  // wave_sums28
     __shared__ int s_done;
     const SweepDesc D = sweeps[b];
     const float4 *sh = sharp + D.sharp_off, *fl = flat + D.flat_off;
     const float4 *gc = geo + D.corr_off, *gs = gc + 2 * (long long)D.nc;  // lo_search_kernel: line points | planes
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6;
     if (threadIdx.x < 6) tr[threadIdx.x] = S.tr[threadIdx.x];
     if (threadIdx.x == 0) s_done = 0;
     __syncthreads();
@@ -1253,11 +1277,7 @@ __global__ __launch_bounds__(LBLOCK) void lo_iter_kernel(
             }
         }
         // ---- block reduction of the 28 sums (fixed order)
-#pragma unroll
-        for (int k = 0; k < LSUMS; ++k) {
-            const double v = wave_sum(sum[k]);
-            if (lane == 0) red[wave][k] = v;
-        }
+        wave_sums28(sum, &s_slab[wave][0], &red[wave][0]);
         __syncthreads();
         if (threadIdx.x == 0) {
             double tot[LSUMS];
