@@ -1334,42 +1334,43 @@ __global__ void lo_finish_kernel(const IterState *__restrict__ st, int nsweeps, 
     if (iters_out) iters_out[b] = st[b].iters;
     if (nsel_out) nsel_out[b] = st[b].nsel;
     if (sum_in && sum_out) {
-        // pose accumulation, LO:1035-1064 with zero IMU terms
+        // pose accumulation, LO:1035-1064 with zero IMU terms.  Every sine / cosine is evaluated once (the expression
+        // as written names cosf(lx) ten times; inlined, that was 12 000 instructions on the odometry half's path)
         const float *S = sum_in + 6 * b;
         const float cx = S[0], cy = S[1], cz = S[2];
         const float lx = -tr[0], ly = (float)(-tr[1] * 1.05), lz = -tr[2];
-        const float srx = cosf(lx) * cosf(cx) * sinf(ly) * sinf(cz) - cosf(cx) * cosf(cz) * sinf(lx) -
-                          cosf(lx) * cosf(ly) * sinf(cx);
+        const float slx = sinf(lx), clx = cosf(lx), sly = sinf(ly), cly = cosf(ly), slz = sinf(lz), clz = cosf(lz);
+        const float scx = sinf(cx), ccx = cosf(cx), scy = sinf(cy), ccy = cosf(cy), scz = sinf(cz), ccz = cosf(cz);
+        const float srx = clx * ccx * sly * scz - ccx * ccz * slx - clx * cly * scx;
         const float ox = -asinf(srx);
-        const float srycrx = sinf(lx) * (cosf(cy) * sinf(cz) - cosf(cz) * sinf(cx) * sinf(cy)) +
-                             cosf(lx) * sinf(ly) * (cosf(cy) * cosf(cz) + sinf(cx) * sinf(cy) * sinf(cz)) +
-                             cosf(lx) * cosf(ly) * cosf(cx) * sinf(cy);
-        const float crycrx = cosf(lx) * cosf(ly) * cosf(cx) * cosf(cy) -
-                             cosf(lx) * sinf(ly) * (cosf(cz) * sinf(cy) - cosf(cy) * sinf(cx) * sinf(cz)) -
-                             sinf(lx) * (sinf(cy) * sinf(cz) + cosf(cy) * cosf(cz) * sinf(cx));
-        const float oy = atan2f(srycrx / cosf(ox), crycrx / cosf(ox));
-        const float srzcrx = sinf(cx) * (cosf(lz) * sinf(ly) - cosf(ly) * sinf(lx) * sinf(lz)) +
-                             cosf(cx) * sinf(cz) * (cosf(ly) * cosf(lz) + sinf(lx) * sinf(ly) * sinf(lz)) +
-                             cosf(lx) * cosf(cx) * cosf(cz) * sinf(lz);
-        const float crzcrx = cosf(lx) * cosf(lz) * cosf(cx) * cosf(cz) -
-                             cosf(cx) * sinf(cz) * (cosf(ly) * sinf(lz) - cosf(lz) * sinf(lx) * sinf(ly)) -
-                             sinf(cx) * (sinf(ly) * sinf(lz) + cosf(ly) * cosf(lz) * sinf(lx));
-        const float oz = atan2f(srzcrx / cosf(ox), crzcrx / cosf(ox));
+        const float cox = cosf(ox);
+        const float srycrx = slx * (ccy * scz - ccz * scx * scy) + clx * sly * (ccy * ccz + scx * scy * scz) +
+                             clx * cly * ccx * scy;
+        const float crycrx = clx * cly * ccx * ccy - clx * sly * (ccz * scy - ccy * scx * scz) -
+                             slx * (scy * scz + ccy * ccz * scx);
+        const float oy = atan2f(srycrx / cox, crycrx / cox);
+        const float srzcrx = scx * (clz * sly - cly * slx * slz) + ccx * scz * (cly * clz + slx * sly * slz) +
+                             clx * ccx * ccz * slz;
+        const float crzcrx = clx * clz * ccx * ccz - ccx * scz * (cly * slz - clz * slx * sly) -
+                             scx * (sly * slz + cly * clz * slx);
+        const float oz = atan2f(srzcrx / cox, crzcrx / cox);
         const float rx = ox, ry = oy, rz = oz;
-        const float x1 = cosf(rz) * tr[3] - sinf(rz) * tr[4];
-        const float y1 = sinf(rz) * tr[3] + cosf(rz) * tr[4];
+        const float s_rx = sinf(rx), c_rx = cox, s_ry = sinf(ry), c_ry = cosf(ry), s_rz = sinf(rz), c_rz = cosf(rz);
+        const float x1 = c_rz * tr[3] - s_rz * tr[4];
+        const float y1 = s_rz * tr[3] + c_rz * tr[4];
         const float z1 = (float)(tr[5] * 1.05);
         const float x2 = x1;
-        const float y2 = cosf(rx) * y1 - sinf(rx) * z1;
-        const float z2 = sinf(rx) * y1 + cosf(rx) * z1;
+        const float y2 = c_rx * y1 - s_rx * z1;
+        const float z2 = s_rx * y1 + c_rx * z1;
         float *O = sum_out + 6 * b;
-        const float acx = -asinf(-sinf(rx));
+        const float acx = -asinf(-s_rx);
+        const float cacx = cosf(acx);
         O[0] = acx;
-        O[1] = atan2f(cosf(rx) * sinf(ry) / cosf(acx), cosf(rx) * cosf(ry) / cosf(acx));
-        O[2] = atan2f(cosf(rx) * sinf(rz) / cosf(acx), cosf(rx) * cosf(rz) / cosf(acx));
-        O[3] = S[3] - (cosf(ry) * x2 + sinf(ry) * z2);
+        O[1] = atan2f(c_rx * s_ry / cacx, c_rx * c_ry / cacx);
+        O[2] = atan2f(c_rx * s_rz / cacx, c_rx * c_rz / cacx);
+        O[3] = S[3] - (c_ry * x2 + s_ry * z2);
         O[4] = S[4] - y2;
-        O[5] = S[5] - (-sinf(ry) * x2 + cosf(ry) * z2);
+        O[5] = S[5] - (-s_ry * x2 + c_ry * z2);
     }
 }
 
