@@ -541,12 +541,12 @@ __device__ __forceinline__ void wave_sums28(const double (&sum)[LSUMS], double *
     }
 }
 
-__device__ __forceinline__ void tile_partial(double (&sum)[LSUMS], double *__restrict__ out)
+// `wslab`: the calling wave's 4 KiB of LDS for the transposes (the search's run-list slab, free by now)
+__device__ __forceinline__ void tile_partial(double (&sum)[LSUMS], double *__restrict__ out, double *__restrict__ wslab)
 {
     __shared__ double red[PT_WAVES][LSUMS];
-    __shared__ double slab[PT_WAVES][8 * 64];
     const int wave = threadIdx.x >> 6;
-    wave_sums28(sum, &slab[wave][0], &red[wave][0]);
+    wave_sums28(sum, wslab, &red[wave][0]);
     __syncthreads();
     if (threadIdx.x < LSUMS) {
         double v = 0;
@@ -707,7 +707,12 @@ __global__ __launch_bounds__(PT_BLOCK) void lm_point_kernel(
             }
         }
     }
-    tile_partial(sum, partial + ((long long)b * tiles_max + tile) * LSUMS);
+#if GPSCAL_LOAM_FLAT
+    tile_partial(sum, partial + ((long long)b * tiles_max + tile) * LSUMS, reinterpret_cast<double *>(slab));
+#else
+    __shared__ double s_red_slab[PT_WAVES][8 * 64];
+    tile_partial(sum, partial + ((long long)b * tiles_max + tile) * LSUMS, &s_red_slab[threadIdx.x >> 6][0]);
+#endif
 }
 
 // one wave per sweep: partials in tile order -> solve -> update (LM:922-1017)
