@@ -962,6 +962,9 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     const bool mono = st[b].mono != 0;
     const bool ring_grids = rcpairs != nullptr && st[b].ring_ok != 0;
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+#ifdef GPSCAL_STATS
+    const unsigned long long t_kernel0 = wall_clock64();
+#endif
     STAT_WAVE(2, 1);  // waves of lo_search_kernel
     const PairDesc &CP = cpairs[b];
     const PairDesc &SP = spairs[b];
@@ -1096,7 +1099,16 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
             int idx;
             float sqd;
             const int prev1 = act ? si1[i] : -1;
+#ifdef GPSCAL_STATS
+            const unsigned long long tk0 = wall_clock64();
+#endif
             lo_nearest_split(SP, ssorted, scells, act, ps, idx, sqd, sl, prev1, slab, s_rd, s_ri);
+#ifdef GPSCAL_STATS
+            if (role == 0) {
+                STAT_WAVE(21, wall_clock64() - tk0);  // surf tiles, wave 0: ticks (10 ns) in the split nearest search
+                STAT_WAVE(10, 1);
+            }
+#endif
             const bool has = act && idx >= 0 && sqd < 25;
             if (has) closest = idx;
             if (role == 0) s_closest[lane] = closest;
@@ -1176,8 +1188,14 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
             R.init(25.f, closest, a0, a1, b0, b1);
             ring_seed(R, has, sl, role == 1 ? prev2 : prev3, ps);
             const bool any = has && (a1 > a0 || b1 > b0);
+#ifdef GPSCAL_STATS
+            const unsigned long long tr0 = wall_clock64();
+#endif
             if (ring_grids) ring_search(rspairs + 16 * b, rssorted, rscells, s_rs_s, any, want, ps, R, slab);
             else knn_query(SP, ssorted, scells, any, ps.x, ps.y, ps.z, R, 0, slab);
+#ifdef GPSCAL_STATS
+            STAT_WAVE(22 + (role == 1 ? 0 : 1), wall_clock64() - tr0);  // 22: own-ring search (wave 1), 23: adjacent rings (waves 2, 3)
+#endif
             s_rd[role][lane] = R.d;
             s_ro[role][lane] = R.ord;
             s_ri[role][lane] = has ? R.i : -1;
@@ -1191,6 +1209,9 @@ __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
             si1[i] = closest;
             si2[i] = min2;
             si3[i] = min3;
+#ifdef GPSCAL_STATS
+            STAT_WAVE(19, wall_clock64() - t_kernel0);  // surf tiles, wave 0: the whole tile
+#endif
             // ... and the unit plane through the three points (LO:847-870), which no iteration changes
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);  // without a full correspondence: pd2 = 0, no row
             if (closest >= 0 && min2 >= 0 && min3 >= 0) {

@@ -26,6 +26,7 @@ for slot, name in ((1, "lo_search_kernel"), (2, "lm_point_kernel")):
     print(name, "waves", c[2], "mono", c[21], "ring grids", c[22], "| level passes (wave)", c[3], "(lane)", c[4], "| rows (wave)", c[5],
           "(lane)", c[6], "| groups of 4 (wave)", c[7], "(lane)", c[16], "| candidates (lane)", c[8], "| levels", c[11:16], flush=True)
 c = [int(buf[1 * NSTAT + k]) for k in range(NSTAT)]
-if c[9] + c[10] > 0:
-    print("lo_search_kernel wave time (10 ns ticks -> us): corner tiles (%d waves) nearest %.1f us, rings %.1f us | surf tiles (%d waves) nearest %.1f us, rings %.1f us" % (
-        c[9], c[19] / max(c[9], 1) / 100.0, c[20] / max(c[9], 1) / 100.0, c[10], c[21] / max(c[10], 1) / 100.0, c[23] / max(c[10], 1) / 100.0))
+if c[10] > 0:
+    n0 = max(c[10], 1)
+    print("lo_search_kernel surf tiles (%d): wave 0 whole tile %.1f us, of which the split nearest search %.1f us; ring searches: own ring (wave 1) %.1f us, adjacent rings (waves 2 + 3, per wave) %.1f us" % (
+        c[10], c[19] / n0 / 100.0, c[21] / n0 / 100.0, c[22] / n0 / 100.0, c[23] / n0 / 200.0))
