@@ -860,7 +860,7 @@ __device__ __forceinline__ void ring_seed(BestRing &R, bool has, const float4 *_
 }
 
 // The nearest search of a tile's 64 features by all four waves of its workgroup: every wave holds the same 64
-// queries and takes some of the 3x3x3 block's nine rows (rows 0-2 | 3-4 | 5-6 | 7-8); after each level the waves join
+// queries; wave 0 scans the own row, then the waves take two of the other eight rows each; after each level the waves join
 // their records through LDS (smaller squared distance, then smaller index: the record's own order), so that all of
 // them decide together whether the level settled the query.  Must be called by the whole workgroup; `act`, `p` and
 // the seed are the same in every wave.  One wave walking all nine rows was the longest chain of the kernel.
@@ -870,7 +870,7 @@ __device__ __forceinline__ void lo_nearest_split(const PairDesc &P, const float4
                                                  uint2 *__restrict__ slab, float (*s_d)[64], int (*s_i)[64])
 {
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
-    const unsigned rowmask = role == 0 ? 0x007u : (role == 1 ? 0x018u : (role == 2 ? 0x060u : 0x180u));
+    const unsigned rowmask = role == 0 ? 0x006u : (role == 1 ? 0x018u : (role == 2 ? 0x060u : 0x180u));  // rows 1-8, two per wave
     Best<1> B;
     B.init_radius(25.f);  // LO:607,758: a nearest point at 5 m or more is no correspondence
     if (act && seed >= 0) {
@@ -898,6 +898,23 @@ __device__ __forceinline__ void lo_nearest_split(const PairDesc &P, const float4
         const GridDesc &G = P.lv[l];
         CellGeo C;
         C.set(G, px, py, pz);
+        // the own row first, by wave 0 alone: its result is the bound with which the four waves then prune the
+        // other eight rows (two each) -- without it they would scan every cell of their rows
+        if (role == 0) {
+            block3_level_flat(G, C, sorted, cell_start, a, px, py, pz, B, slab, 0x001u);
+            s_d[0][lane] = B.d[0];
+            s_i[0][lane] = B.i[0];
+        }
+        __syncthreads();
+        if (role != 0) {
+            const float d = s_d[0][lane];
+            const int i = s_i[0][lane];
+            if (d < B.d[0] || (d == B.d[0] && i < B.i[0])) {
+                B.d[0] = d;
+                B.i[0] = i;
+            }
+        }
+        __syncthreads();
         block3_level_flat(G, C, sorted, cell_start, a, px, py, pz, B, slab, rowmask);
         s_d[role][lane] = B.d[0];
         s_i[role][lane] = B.i[0];
