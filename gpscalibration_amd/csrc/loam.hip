@@ -935,12 +935,14 @@ __device__ __forceinline__ void lo_nearest_split(const PairDesc &P, const float4
     sqd = B.d[0];
 }
 
-// A tile is 64 features and a workgroup its four waves: wave 0 finds every feature's nearest point of the last
-// cloud; the adjacent-ring searches need only that result and are independent of each other, so after a barrier
-// waves 1..3 run one of them each (corner: rings scan-1 | scan+1 -> min2; surf: own ring -> min2, rings scan-1 |
-// scan+1 -> min3) and wave 0 joins the partial records in the record's own order (squared distance, then the order
-// the sequential walk would meet the candidates).  One after the other in one lane they were a chain of ~160 us at
-// under one wave per SIMD; side by side the launch is as long as the nearest search plus ONE ring search.
+// A tile is 64 features and a workgroup its four waves, which all hold the same 64 queries.  The nearest point of
+// the last cloud is searched by all of them (lo_nearest_split: wave 0 the own row of the 3x3x3 block, then two of the
+// other eight rows per wave, records joined through LDS after every level).  The adjacent-ring searches need only
+// that result and are independent of each other, so after a barrier waves 1..3 run one of them each (corner: rings
+// scan-1 | scan+1 -> min2; surf: own ring -> min2, rings scan-1 | scan+1 -> min3) and wave 0 joins the partial
+// records in the record's own order (squared distance, then the order the sequential walk would meet the
+// candidates) and leaves the correspondence's geometry for lo_iter_kernel.  One after the other in one lane these
+// searches were a chain of ~160 us at under one wave per SIMD.
 constexpr int LO_TILE = 64;
 __global__ __launch_bounds__(PT_BLOCK) void lo_search_kernel(
     const SweepDesc *__restrict__ sweeps, const float4 *__restrict__ sharp, const float4 *__restrict__ flat,
