@@ -54,20 +54,32 @@ __global__ void pack_points_kernel(const char *__restrict__ raw, int stride, con
     out[i] = make_float4(p[0], p[1], p[2], __int_as_float((int)(i - offs[lo])));
 }
 
-// bbox[pair][6] holds order-preserving int keys: min xyz then max xyz.
-__global__ void bbox_kernel(const float4 *__restrict__ pts, const long long *__restrict__ offs,
-                            int *__restrict__ bbox)
+// bbox[pair][6] holds order-preserving int keys: min xyz then max xyz.  One set of six atomics per workgroup
+// (the waves meet in LDS first) and BB_PT points per thread: with an atomic set per wave of 4 points per lane,
+// 64 x 65 536 points put 256 atomics on every address and the kernel ran at 0.5 TB/s (143 us).
+constexpr int BB_PT = 16;
+__global__ __launch_bounds__(BLOCK) void bbox_kernel(const float4 *__restrict__ pts, const long long *__restrict__ offs,
+                                                      int *__restrict__ bbox)
 {
+    __shared__ float s_box[BLOCK / 64][6];
     int b = blockIdx.y;
     long long o = offs[b];
     int m = (int)(offs[b + 1] - o);
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        float4 p = pts[o + i];
-        if (!finite3(p.x, p.y, p.z)) continue;
-        mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-        mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-        mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+    for (int i0 = blockIdx.x * BLOCK * 4 + threadIdx.x; i0 < m; i0 += gridDim.x * BLOCK * 4) {
+        float4 p[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // four loads in flight
+            const int i = i0 + t * BLOCK;
+            p[t] = i < m ? pts[o + i] : make_float4(NAN, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (!finite3(p[t].x, p[t].y, p[t].z)) continue;
+            mn[0] = fminf(mn[0], p[t].x); mx[0] = fmaxf(mx[0], p[t].x);
+            mn[1] = fminf(mn[1], p[t].y); mx[1] = fmaxf(mx[1], p[t].y);
+            mn[2] = fminf(mn[2], p[t].z); mx[2] = fmaxf(mx[2], p[t].z);
+        }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -77,12 +89,21 @@ __global__ void bbox_kernel(const float4 *__restrict__ pts, const long long *__r
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], s));
         }
     }
-    if ((threadIdx.x & 63) == 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&bbox[b * 6 + a], f2ord(mn[a]));
-            atomicMax(&bbox[b * 6 + 3 + a], f2ord(mx[a]));
+            s_box[wave][a] = mn[a];
+            s_box[wave][3 + a] = mx[a];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s_box[0][threadIdx.x];
+        for (int w = 1; w < BLOCK / 64; ++w)
+            v = threadIdx.x < 3 ? fminf(v, s_box[w][threadIdx.x]) : fmaxf(v, s_box[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&bbox[b * 6 + threadIdx.x], f2ord(v));
+        else atomicMax(&bbox[b * 6 + threadIdx.x], f2ord(v));
     }
 }
 
@@ -642,7 +663,7 @@ __global__ void gather_weights_kernel(const PairDesc *__restrict__ pairs, const 
 // Puts the points of every cell of a one-level grouping into original-index order.  The counting sort hands
 // out the slots of a cell with integer atomics, so the order inside a cell would otherwise differ from build
 // to build -- and with it the order in which the step kernel adds the float64 sums.  One lane per cell
-// (insertion sort, runs of <= 64); a wave takes the runs of 65..512 together (rank of every element, then one
+// (rank sort in registers up to 16 points, one wave with an element per lane up to 64); a wave takes the runs of 65..512 together (rank of every element, then one
 // scatter); longer runs (more than 512 points in one cell: degenerate input) stay as they are.
 __global__ __launch_bounds__(BLOCK) void order_runs_kernel(float4 *__restrict__ sorted,
                                                             const unsigned *__restrict__ cell_start, long long ncells)
@@ -653,21 +674,50 @@ __global__ __launch_bounds__(BLOCK) void order_runs_kernel(float4 *__restrict__ 
         s = cell_start[c];
         n = cell_start[c + 1] - s;
     }
-    if (n >= 2 && n <= 64) {
-        for (unsigned a = 1; a < n; ++a) {
-            const float4 key = sorted[s + a];
-            const int ki = __float_as_int(key.w);
-            unsigned b = a;
-            while (b > 0) {
-                const float4 prev = sorted[s + b - 1];
-                if (__float_as_int(prev.w) <= ki) break;
-                sorted[s + b] = prev;
-                --b;
-            }
-            sorted[s + b] = key;
+    // Runs of up to OR_REG points: all of them loaded at once, ranked in registers (indices are distinct), each
+    // written to its place.  The insertion sort below walks a chain of dependent global loads (n^2 / 4 of them)
+    // and is left to the few longer runs: with it alone the kernel took 434 us for 64 x 65 536 points.
+    constexpr int OR_REG = 16;
+    if (n >= 2 && n <= 4) {
+        float4 e[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e[t] = t < (int)n ? sorted[s + t] : make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            unsigned r = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r += __float_as_int(e[u].w) < __float_as_int(e[t].w) ? 1u : 0u;
+            if (t < (int)n && r != (unsigned)t) sorted[s + r] = e[t];
+        }
+    } else if (n > 4 && n <= OR_REG) {
+        float4 e[OR_REG];
+#pragma unroll
+        for (int t = 0; t < OR_REG; ++t)
+            e[t] = t < (int)n ? sorted[s + t] : make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
+#pragma unroll
+        for (int t = 0; t < OR_REG; ++t) {
+            unsigned r = 0;
+#pragma unroll
+            for (int u = 0; u < OR_REG; ++u) r += __float_as_int(e[u].w) < __float_as_int(e[t].w) ? 1u : 0u;
+            if (t < (int)n && r != (unsigned)t) sorted[s + r] = e[t];
         }
     }
     const int lane = threadIdx.x & 63;
+    // runs of OR_REG+1 .. 64 points (dense cells: poles, wall feet): one element per lane of the owner's wave, the
+    // other elements' indices come by readlane -- no dependent memory traffic either
+    unsigned long long m64 = __ballot(n > OR_REG && n <= 64);
+    while (m64) {  // wave-uniform
+        const int owner = __builtin_ctzll(m64);
+        m64 &= m64 - 1;
+        const unsigned ss = __builtin_amdgcn_readlane(s, owner), nn = __builtin_amdgcn_readlane(n, owner);
+        float4 el = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
+        if ((unsigned)lane < nn) el = sorted[ss + lane];
+        const int my = __float_as_int(el.w);
+        unsigned rk = 0;
+        for (unsigned j = 0; j < nn; ++j) rk += __builtin_amdgcn_readlane(my, j) < my ? 1u : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if ((unsigned)lane < nn && rk != (unsigned)lane) sorted[ss + rk] = el;
+    }
     unsigned long long m = __ballot(n > 64 && n <= 512);
     while (m) {  // wave-uniform
         const int owner = __builtin_ctzll(m);
@@ -835,7 +885,7 @@ int build_grids_multi(gpscal_ctx *ctx, int nsrc, const GridSource *src, int stri
             pb += src[k].npairs;
         }
         // bounding boxes
-        const int gx = std::max(1, std::min(div_up(W.mmax, BLOCK * 4), 256));
+        const int gx = std::max(1, std::min(div_up(W.mmax, BLOCK * BB_PT), 256));
         if (W.npairs > 0 && W.mmax > 0)
             hipLaunchKernelGGL(bbox_kernel, dim3(gx, W.npairs), dim3(BLOCK), 0, ctx->stream, gs.pts4.p, W.d_off.p,
                                d_bbox.p + W.bbox_at * 6);
@@ -930,8 +980,9 @@ int ensure_safe_radius(gpscal_ctx *ctx, GridSet &gs)
 {
     if (gs.pt_r2.p) return GPSCAL_OK;
     const long long total = gs.off[gs.npairs] - gs.off[0];
-    GPSCAL_HIP(ctx, gs.nbr.alloc((size_t)std::max<long long>(total, 1) * 4));
-    GPSCAL_HIP(ctx, gs.pt_r2.alloc((size_t)std::max<long long>(total, 1)));
+    const size_t slots = (size_t)std::max<long long>(total, 1);
+    GPSCAL_HIP(ctx, gs.pooled ? gs.nbr.alloc_async(slots * 4, ctx->stream) : gs.nbr.alloc(slots * 4));
+    GPSCAL_HIP(ctx, gs.pooled ? gs.pt_r2.alloc_async(slots, ctx->stream) : gs.pt_r2.alloc(slots));
     // non-finite points are never indexed nor returned: their slots stay zero
     GPSCAL_HIP(ctx, hipMemsetAsync(gs.nbr.p, 0, sizeof(float4) * 4 * (size_t)std::max<long long>(total, 1), ctx->stream));
     GPSCAL_HIP(ctx, hipMemsetAsync(gs.pt_r2.p, 0, sizeof(float2) * (size_t)std::max<long long>(total, 1), ctx->stream));
@@ -1177,33 +1228,33 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
             B->chain_ev[c] = ctx->side_event[c];
         }
     }
-    GPSCAL_HIP(ctx, B->blk_pair.alloc(bp.size()));
-    GPSCAL_HIP(ctx, B->blk_first.alloc(bf.size()));
+    GPSCAL_HIP(ctx, B->blk_pair.alloc_async(bp.size(), ctx->stream));
+    GPSCAL_HIP(ctx, B->blk_first.alloc_async(bf.size(), ctx->stream));
     if (!bp.empty()) {
         GPSCAL_HIP(ctx, hipMemcpyAsync(B->blk_pair.p, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice, ctx->stream));
         GPSCAL_HIP(ctx, hipMemcpyAsync(B->blk_first.p, bf.data(), sizeof(int) * bf.size(), hipMemcpyHostToDevice, ctx->stream));
     }
-    GPSCAL_HIP(ctx, B->pairs.alloc(np));
+    GPSCAL_HIP(ctx, B->pairs.alloc_async(np, ctx->stream));
     GPSCAL_HIP(ctx, hipMemcpyAsync(B->pairs.p, B->hpairs.data(), sizeof(PairDesc) * np, hipMemcpyHostToDevice, ctx->stream));
     B->weighted = w != nullptr;
     if (w) {
         InArg<double> win;
         GPSCAL_HIP(ctx, win.bind(ctx, w, (size_t)B->total_n));
-        GPSCAL_HIP(ctx, B->wsorted.alloc((size_t)B->total_n));
+        GPSCAL_HIP(ctx, B->wsorted.alloc_async((size_t)B->total_n, ctx->stream));
         int gx = std::max(1, std::min(div_up(maxn, BLOCK), 1024));
         hipLaunchKernelGGL(gather_weights_kernel, dim3(gx, np), dim3(BLOCK), 0, ctx->stream, B->pairs.p, B->src4.p,
                            win.dev, B->wsorted.p);
         GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    GPSCAL_HIP(ctx, B->nn_idx.alloc((size_t)std::max<long long>(B->total_n, 1)));
-    GPSCAL_HIP(ctx, B->nn_sqd.alloc((size_t)std::max<long long>(B->total_n, 1)));
-    GPSCAL_HIP(ctx, B->warm_q.alloc((size_t)std::max<long long>(B->total_n, 1)));
-    GPSCAL_HIP(ctx, B->warm_r2.alloc((size_t)std::max<long long>(B->total_n, 1)));
+    GPSCAL_HIP(ctx, B->nn_idx.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
+    GPSCAL_HIP(ctx, B->nn_sqd.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
+    GPSCAL_HIP(ctx, B->warm_q.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
+    GPSCAL_HIP(ctx, B->warm_r2.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
     hipLaunchKernelGGL(fill_warm_kernel, dim3(div_up(std::max<long long>(B->total_n, 1), BLOCK)), dim3(BLOCK), 0,
                        ctx->stream, B->warm_q.p, B->warm_r2.p, B->total_n);
-    GPSCAL_HIP(ctx, B->partials.alloc((size_t)std::max(B->nblk, 1) * NACC_WEIGHTED));
-    GPSCAL_HIP(ctx, B->pose64.alloc((size_t)np * 16));
-    GPSCAL_HIP(ctx, B->pose32.alloc((size_t)np * 12));
+    GPSCAL_HIP(ctx, B->partials.alloc_async((size_t)std::max(B->nblk, 1) * NACC_WEIGHTED, ctx->stream));
+    GPSCAL_HIP(ctx, B->pose64.alloc_async((size_t)np * 16, ctx->stream));
+    GPSCAL_HIP(ctx, B->pose32.alloc_async((size_t)np * 12, ctx->stream));
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return gpscal_scan_batch_set_pose(B, nullptr);
 }
@@ -1220,6 +1271,10 @@ extern "C" int gpscal_scan_batch_create(gpscal_ctx *ctx, int npairs, const float
     B->ctx = ctx;
     B->npairs = npairs;
     B->tgt = new GridSet;
+    // a batch's own index and state are blocks of the stream's cache: a stream of batches of one shape (one per
+    // sweep) then allocates nothing after the first (a hipMalloc of these sizes costs ~0.2 ms, sixteen of them
+    // were a third of the build); the batch is used on the context's streams only and destroyed after a sync
+    B->tgt->pooled = true;
     std::vector<long long> to(tgt_off, tgt_off + npairs + 1), so(src_off, src_off + npairs + 1);
     auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t) {
         if (getenv("GPSCAL_BUILD_TIMING")) {
@@ -1333,7 +1388,7 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
     const bool want_err = mean_err != nullptr;  // without it the step kernel skips the distance sum (a float64 sqrt per query)
     if (iters > B->err_cap) {
         B->drop_graphs();  // they hold the old error-history pointer
-        GPSCAL_HIP(ctx, B->err_hist.alloc((size_t)np * iters));
+        GPSCAL_HIP(ctx, B->err_hist.alloc_async((size_t)np * iters, ctx->stream));
         B->err_cap = iters;
     }
     if (step_ms) {
