@@ -300,12 +300,21 @@ __global__ __launch_bounds__(BLOCK) void knn_search_kernel(const PairDesc *__res
 //                 the 4 listed points (everything else is at least D5 from q0).
 // D1 / D5 = distance from q0 to its nearest / 5th nearest other point.  The 0.99 factor
 // absorbs the float rounding of the three distances involved.
+#ifndef GPSCAL_SELF_NN_FLAT
+#define GPSCAL_SELF_NN_FLAT 1
+#endif
 __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restrict__ pairs,
                                                          const float4 *__restrict__ sorted,
                                                          const unsigned *__restrict__ cell_start,
                                                          const float4 *__restrict__ pts4, float4 *__restrict__ nbr,
                                                          float2 *__restrict__ pt_r2)
 {
+#if GPSCAL_SELF_NN_FLAT
+    __shared__ uint2 s_slab[BLOCK / 64][8 * 64];  // per wave: the run lists of block3_level_flat
+    uint2 *slab = &s_slab[threadIdx.x >> 6][0];
+#else
+    uint2 *slab = nullptr;
+#endif
     const int b = blockIdx.y;
     const PairDesc &P = pairs[b];
     // level-0 block of this pair = positions [first0, end0)
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
         if (act) c = sorted[j];
         Best<6> B;
         B.init();
-        knn_query(P, sorted, cell_start, act, c.x, c.y, c.z, B);
+        knn_query(P, sorted, cell_start, act, c.x, c.y, c.z, B, 0, slab);
         if (!act) continue;
         const int own = __float_as_int(c.w);
         const long long g = P.tgt_off + own;
