@@ -45,6 +45,11 @@
  *     worker thread and one extra stream for the duration of the call and
  *     join / destroy them before they return (GPSCAL_LOAM_PIPELINE=0 keeps
  *     everything on the calling thread; the results are identical);
+ *   - device memory: per-call temporaries and the state of a scan batch are
+ *     blocks of a cache the library keeps per stream (no hipMalloc / hipFree,
+ *     and so no device-wide synchronisation, once the sizes have been seen);
+ *     at most 8 GiB of idle blocks stay cached per stream, gpscal_destroy
+ *     returns them.  A scan batch must be destroyed before its context;
  *   - there is NO CPU fallback: without a usable gfx950 device gpscal_create
  *     fails with GPSCAL_ENODEV and nothing else can be called.
  *
