@@ -561,6 +561,17 @@ def test_weights_match_oracle(ctx):
     np.testing.assert_allclose(wi, O.weights_irls(slam, enu, cal), rtol=1e-14)
 
 
+def test_weights_known_answer(ctx):
+    # weight_calculation.cc:4-27, 30-78 evaluated by hand (the same case as test_oracle_cpu.test_irls_weights_known_answer):
+    # speed weights 1, 1.1 / 2.2, min(4.4 / 2.2, 1), 1; residuals 0.5, 0.005 (clamped to 0.01), 2, 0.25
+    slam = np.array([[0, 0, 10, 0], [0.55, 0, 10, 1], [0.55, 1.1, 10, 2], [0.55, 5.5, 10, 3]], dtype=np.float64)
+    fit = np.array([[5, 7, 10, 0], [6, 7, 10, 1], [6, 8, 10, 2], [6, 12, 10, 3]], dtype=np.float64)
+    enu = fit.copy()
+    enu[:, 0] += [0.5, 0.005, 2.0, 0.25]
+    assert ctx.weights_speed(slam).tolist() == [1.0, 0.5, 1.0, 1.0]
+    np.testing.assert_allclose(ctx.weights_irls(slam, enu, fit), [2.0, 50.0, 0.5, 4.0], rtol=1e-15)
+
+
 def test_gps_to_enu_and_back_match_oracle(ctx, gps_log_bytes):
     st = 1494650700.0 + np.arange(1000)
     slam = np.zeros((1000, 4))

@@ -112,6 +112,33 @@ def test_utm_forward_close_to_krueger():
         assert abs(xy[i, 1] - (e + 500000 + 40 * 1e7)) < 0.02
 
 
+def test_gauss_forward_on_the_shipped_log_close_to_krueger(gps_log_bytes):
+    # "Gaussion" (gps_process.cc:953-1007) on fixes of the log the reference ships, against the independent
+    # Krueger series with k0 = 1: northing and (easting + 500 km + band * 10^7) within a centimetre.
+    lat, lon, _ = O.parse_gprmc(gps_log_bytes, 1494650697.0, 1494653187.0)
+    pick = np.arange(0, len(lat), 311)
+    xy = O.wgs_to_local(lat[pick], lon[pick], 1, 3)
+    for k, i in enumerate(pick):
+        n, e = _krueger_tm(lat[i], lon[i], 120.0, 1.0, b=6356752.3142)
+        assert abs(xy[k, 0] - n) < 0.01, (i, xy[k, 0] - n)
+        assert abs(xy[k, 1] - (e + 500000 + 40 * 1e7)) < 0.01, (i, xy[k, 1] - e)
+
+
+def test_irls_weights_known_answer():
+    # weight_calculation.cc:30-78 by hand on a 4-point track: speed weights 1 (first point), |p2 - p1| / 2.2 =
+    # 1.1 / 2.2 = 0.5, min(4.4 / 2.2, 1) = 1, last point = its distance from the origin / 2.2 capped at 1
+    # (SURVEY 8c); residuals |E - F| = 0.5, 0.005 (clamped to 0.01), 2, 0.25 -> factors 2, 100, 0.5, 4.
+    slam = np.array([[0, 0, 10, 0], [0.55, 0, 10, 1], [0.55, 1.1, 10, 2], [0.55, 5.5, 10, 3]], dtype=np.float64)
+    fit = np.array([[5, 7, 10, 0], [6, 7, 10, 1], [6, 8, 10, 2], [6, 12, 10, 3]], dtype=np.float64)
+    enu = fit.copy()
+    enu[:, 0] += [0.5, 0.005, 2.0, 0.25]
+    assert O.weights_speed(slam).tolist() == [1.0, 0.5, 1.0, 1.0]
+    assert O.weights_irls(slam, enu, fit).tolist() == KNOWN_IRLS
+
+
+KNOWN_IRLS = [2.0, 50.0, 0.5, 4.0]
+
+
 def test_projection_round_trip_all_methods():
     rng = np.random.default_rng(1)
     lat = 31.0 + rng.uniform(-0.5, 0.5, 200)
