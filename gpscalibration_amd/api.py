@@ -289,10 +289,10 @@ class Context:
                  "voxel_grid_batched")
         return [out[off[c]:off[c] + cnt[c]].copy() for c in range(nc)]
 
-    def loam_run(self, segments, stamps, corner_pool_cap=0, surf_pool_cap=0):
-        """The four LOAM nodes over pre-cut segments.  `segments` = list (one per segment) of lists of raw
-        sweeps [n,3] float32; `stamps` = list of per-segment stamp arrays.  Returns a list of dicts
-        (lo_sum, lm_aft, tm_mapped [n,6] float32; track [n,4] float64; lm_iters [n] int32) per segment."""
+    @staticmethod
+    def loam_pack(segments, stamps):
+        """The argument arrays of gpscal_loam_run_batched for `segments` = list (one per segment) of lists of raw
+        sweeps [n,3] float32 and `stamps` = list of per-segment stamp arrays: (xyz, off, seg_off, stamps)."""
         nseg = len(segments)
         flat = [sw for seg in segments for sw in seg]
         nsw = len(flat)
@@ -302,6 +302,12 @@ class Context:
         off[1:] = np.cumsum([len(a) for a in flat])
         xyz = np.ascontiguousarray(np.concatenate(flat), dtype=np.float32)
         st = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64) for x in stamps]))
+        return xyz, off, seg_off, st
+
+    def loam_run_packed(self, packed, corner_pool_cap=0, surf_pool_cap=0):
+        """gpscal_loam_run_batched on arrays from loam_pack; `xyz` may be a torch tensor in HBM (used in place)."""
+        xyz, off, seg_off, st = packed
+        nseg, nsw = len(seg_off) - 1, len(off) - 1
         lo = np.empty((nsw, 6), dtype=np.float32)
         lm = np.empty((nsw, 6), dtype=np.float32)
         tm = np.empty((nsw, 6), dtype=np.float32)
@@ -316,6 +322,12 @@ class Context:
             out.append({"lo_sum": lo[a:b], "lm_aft": lm[a:b], "tm_mapped": tm[a:b], "track": track[a:b],
                         "lm_iters": iters[a:b]})
         return out
+
+    def loam_run(self, segments, stamps, corner_pool_cap=0, surf_pool_cap=0):
+        """The four LOAM nodes over pre-cut segments.  `segments` = list (one per segment) of lists of raw
+        sweeps [n,3] float32; `stamps` = list of per-segment stamp arrays.  Returns a list of dicts
+        (lo_sum, lm_aft, tm_mapped [n,6] float32; track [n,4] float64; lm_iters [n] int32) per segment."""
+        return self.loam_run_packed(self.loam_pack(segments, stamps), corner_pool_cap, surf_pool_cap)
 
     def input_data_run(self, bags, stamps, long_distance, short_distance, overlap_distance, corner_pool_cap=0,
                        surf_pool_cap=0):

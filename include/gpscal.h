@@ -48,8 +48,9 @@
  *   - device memory: per-call temporaries and the state of a scan batch are
  *     blocks of a cache the library keeps per stream (no hipMalloc / hipFree,
  *     and so no device-wide synchronisation, once the sizes have been seen);
- *     at most 8 GiB of idle blocks stay cached per stream, gpscal_destroy
- *     returns them.  A scan batch must be destroyed before its context;
+ *     at most an eighth of the device memory (8 GiB at least) stays cached
+ *     idle per stream, gpscal_destroy returns it.  A scan batch must be
+ *     destroyed before its context;
  *   - there is NO CPU fallback: without a usable gfx950 device gpscal_create
  *     fails with GPSCAL_ENODEV and nothing else can be called.
  *
