@@ -27,7 +27,7 @@ struct BlockShared {
     int overflow;
     // voxel grid
     float red[SWAVES][6];
-    int vg_minb[3], vg_mul[3], vg_copy, vg_m;
+    int vg_minb[3], vg_mul[3], vg_copy, vg_m, vg_div2;
 };
 
 // rank of this thread among the threads with flag set (thread order), and the block total
@@ -75,6 +75,66 @@ __device__ inline void block_bitonic_sort(unsigned long long *K, int np2)
         }
 }
 
+// Stable LSD radix sort of the 64-bit keys K[0, n) by bits [32, 32 + bits) -- the voxel number of block_voxel_grid's
+// keys (cell << 32 | input index; the keys come in input order, so a stable sort by the cell IS the sort by the whole
+// key) -- by the whole workgroup, 4 bits per pass, T[0, n) as the second buffer; the result ends in K.  Thread t owns
+// the keys [t c, (t + 1) c): it counts its digits into its own column of cnt[16][SBLOCK] (32 KiB of LDS), an
+// exclusive scan over the 8 192 counters in (digit, thread) order gives every (digit, thread) its first slot, and
+// the thread moves its keys in order.  ~2 (bits / 4) sweeps over the keys against log2(n)^2 / 2 of the bitonic
+// network: clouds above the LDS sort size no longer pay ~100 passes of one workgroup over global memory.
+__device__ inline void block_radix_sort_cells(BlockShared &S, unsigned long long *K, unsigned long long *T, int n,
+                                              int bits, unsigned *cnt)
+{
+    const int c = (n + SBLOCK - 1) / SBLOCK;
+    const int i0 = min(n, (int)threadIdx.x * c), i1 = min(n, i0 + c);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long *src = K, *dst = T;
+    for (int shift = 32; shift < 32 + bits; shift += 4) {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) cnt[d * SBLOCK + threadIdx.x] = 0u;
+        for (int i = i0; i < i1; ++i) cnt[(int)((src[i] >> shift) & 15ull) * SBLOCK + threadIdx.x] += 1u;
+        __syncthreads();
+        // exclusive scan of cnt[0, 16 * SBLOCK): 16 consecutive counters per thread, then the threads' sums
+        unsigned loc[16], sum = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            loc[k] = cnt[threadIdx.x * 16 + k];
+            sum += loc[k];
+        }
+        unsigned inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        if (lane == 63) S.wcnt[wave][0] = (int)inc;
+        __syncthreads();
+        unsigned before = inc - sum;
+#pragma unroll
+        for (int w = 0; w < SWAVES; ++w) before += w < wave ? (unsigned)S.wcnt[w][0] : 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            cnt[threadIdx.x * 16 + k] = before;
+            before += loc[k];
+        }
+        __syncthreads();
+        for (int i = i0; i < i1; ++i) {
+            const unsigned long long k = src[i];
+            const int slot = (int)((k >> shift) & 15ull) * SBLOCK + threadIdx.x;
+            dst[cnt[slot]] = k;
+            cnt[slot] += 1u;
+        }
+        __syncthreads();
+        unsigned long long *t = src;
+        src = dst;
+        dst = t;
+    }
+    if (src != K) {
+        for (int i = threadIdx.x; i < n; i += SBLOCK) K[i] = src[i];
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ bool get_bit(unsigned *bits, int i)
 {
     return (__hip_atomic_load(&bits[i >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (i & 31)) & 1u;
@@ -117,7 +177,7 @@ __device__ __forceinline__ bool fin3(float x, float y, float z) { return isfinit
 // Called by every thread of the workgroup; *count is a workgroup-shared counter.
 __device__ inline void block_voxel_grid(BlockShared &S, const float4 *__restrict__ src, int n, float leaf,
                                  float4 *__restrict__ dst, int cap, int *count, unsigned long long *lds_keys,
-                                 unsigned long long *g_keys, int g_cap)
+                                 unsigned long long *g_keys, int g_cap, int lds_cap = LDS_KEYS)
 {
     if (n <= 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -167,6 +227,7 @@ __device__ inline void block_voxel_grid(BlockShared &S, const float4 *__restrict
             S.vg_mul[0] = 1;
             S.vg_mul[1] = divb[0];
             S.vg_mul[2] = divb[0] * divb[1];
+            S.vg_div2 = divb[2];
         }
     }
     __syncthreads();
@@ -182,12 +243,17 @@ __device__ inline void block_voxel_grid(BlockShared &S, const float4 *__restrict
         __syncthreads();
         return;
     }
-    const int np2 = next_pow2(n);
-    unsigned long long *K = np2 <= LDS_KEYS ? lds_keys : g_keys;
-    if (np2 > LDS_KEYS && np2 > g_cap) {  // host sized the scratch from the input counts; cannot happen
+    int np2 = next_pow2(n);
+    // `lds_cap`: keys the caller's LDS buffer holds (a kernel launched with more dynamic LDS sorts larger clouds there)
+    unsigned long long *K = np2 <= lds_cap ? lds_keys : g_keys;
+    if (np2 > lds_cap && np2 > g_cap) {  // host sized the scratch from the input counts; cannot happen
         S.overflow = 1;
         return;
     }
+    // above the LDS size, with room for a second key buffer: radix sort by the voxel number instead of the bitonic
+    // network in global memory (no padding to a power of two then)
+    const bool radix = np2 > lds_cap && g_cap >= 2 * n;
+    if (radix) np2 = n;
     for (int i = threadIdx.x; i < np2; i += SBLOCK) {
         unsigned long long key = ~0ull;
         if (i < n) {
@@ -203,7 +269,15 @@ __device__ inline void block_voxel_grid(BlockShared &S, const float4 *__restrict
         K[i] = key;
     }
     __syncthreads();
-    block_bitonic_sort(K, np2);
+    if (radix) {
+        // bits: 2^bits > number of voxels, so a non-finite point's all-ones key sorts behind every voxel
+        const long long cells = (long long)S.vg_mul[2] * S.vg_div2;
+        int bits = 1;
+        while (bits < 32 && (1ll << bits) <= cells) ++bits;
+        block_radix_sort_cells(S, K, g_keys + n, n, bits, reinterpret_cast<unsigned *>(lds_keys));
+    } else {
+        block_bitonic_sort(K, np2);
+    }
     // one thread per run of equal cell ids
     const int base = *count;
     __syncthreads();

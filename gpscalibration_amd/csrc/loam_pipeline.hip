@@ -296,6 +296,12 @@ struct PrepDesc {
 // LM:420-745 for one segment: state reset, transformAssociateToMap, ring shift, FOV cube list,
 // map assembly, stack transform + voxel filters.  sizes[s] = {map corner, map surf, stack corner,
 // stack surf}.
+// The VoxelGrid filters of laserMapping (the stack of a sweep: 3-8 k points; a cube of the map: old + new points)
+// sort their keys by one workgroup.  Up to LM_LDS_KEYS keys that happens in LDS (128 KiB of the CU's 160: these
+// kernels run one workgroup per stream or per cube anyway); with the 4 096 keys of the other kernels' 32 KiB the
+// larger clouds took the HBM path of block_bitonic_sort -- ~100 passes of one workgroup over global memory,
+// 0.6 ms (`lm_prepare_kernel`) and 0.85 ms (`lm_filter_kernel`) per mapping step of the bench's bag -> KML run.
+constexpr int LM_LDS_KEYS = 16384;
 __global__ __launch_bounds__(SBLOCK) void lm_prepare_kernel(const PrepDesc *__restrict__ descs, SegState *__restrict__ st,
                                                             PipeDims dims, PipeBufs B, const float4 *__restrict__ clast,
                                                             const float4 *__restrict__ slast, int *__restrict__ sizes,
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(SBLOCK) void lm_prepare_kernel(const PrepDesc *__re
         __syncthreads();
         block_voxel_grid(S, s2, n, type == 0 ? 0.2f : 0.4f, B.stack[type] + (long long)s * dims.stack_cap[type],
                          dims.stack_cap[type], &s_cnt, dyn_lds, B.keys[type] + (long long)s * dims.key_cap[type],
-                         dims.key_cap[type]);
+                         dims.key_cap[type], LM_LDS_KEYS);
         __syncthreads();
         if (threadIdx.x == 0) sizes[4 * s + 2 + type] = s_cnt;
         __syncthreads();
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(SBLOCK) void lm_filter_kernel(const SegState *__res
     __syncthreads();
     block_voxel_grid(S, B.vin[type] + (long long)s * vcap + off, n, type == 0 ? 0.2f : 0.4f,
                      B.vout[type] + (long long)s * vcap + off, n, &s_cnt, dyn_lds,
-                     B.vkeys[type] + 2 * ((long long)s * vcap + off), 2 * max(n, 1));
+                     B.vkeys[type] + 2 * ((long long)s * vcap + off), 2 * max(n, 1), LM_LDS_KEYS);
     __syncthreads();
     if (threadIdx.x == 0) {
         B.vout_cnt[type][(long long)s * MAXVALID + k] = s_cnt;
@@ -908,6 +914,20 @@ struct LoamPipe {
         sweep_off = sweep_off_;
         h_stamps = stamps;
         hipStream_t q = ctx->stream;
+        {
+            // more than the default 64 KiB of dynamic LDS needs the attribute (per process, any thread)
+            static std::once_flag lds_once;
+            static hipError_t lds_err = hipSuccess;
+            std::call_once(lds_once, [] {
+                const int bytes = (int)(sizeof(unsigned long long) * LM_LDS_KEYS);
+                lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_prepare_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                if (lds_err == hipSuccess)
+                    lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_filter_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            });
+            GPSCAL_HIP(ctx, lds_err);
+        }
         const size_t npts = (size_t)std::max(sweep_off[nsw], 1);
         GPSCAL_HIP(ctx, a_xyz.bind(ctx, xyz, npts * 3));
         DevBuf<float4> d_full;
@@ -1207,7 +1227,7 @@ struct LoamPipe {
         const int nseg = nstream;
         SegState *S = d_state.p;
         const int buf = L.buf;
-        const size_t lds_keys = sizeof(unsigned long long) * LDS_KEYS;
+        const size_t lds_keys = sizeof(unsigned long long) * LDS_KEYS, lm_lds = sizeof(unsigned long long) * LM_LDS_KEYS;
         const std::vector<long long> &coff = L.coff, &soff = L.soff;
         if (L.any_map) {
             for (int s = 0; s < nseg; ++s) {
@@ -1222,7 +1242,7 @@ struct LoamPipe {
             }
             GPSCAL_HIP(ctx, hipMemcpyAsync(d_rows.p, hrows.data(), sizeof(int) * nseg, hipMemcpyHostToDevice, q));
             GPSCAL_HIP(ctx, hipMemcpyAsync(d_prep.p, hprep.data(), sizeof(PrepDesc) * nseg, hipMemcpyHostToDevice, q));
-            hipLaunchKernelGGL(lm_prepare_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, d_prep.p, S, dims, B,
+            hipLaunchKernelGGL(lm_prepare_kernel, dim3(nseg), dim3(SBLOCK), lm_lds, q, d_prep.p, S, dims, B,
                                d_clast[buf].p, d_slast[buf].p, d_sizes.p, d_status.p, d_step_lo[buf].p);
             GPSCAL_HIP(ctx, hipGetLastError());
             GPSCAL_HIP(ctx, hipMemcpyAsync(hsizes.data(), d_sizes.p, sizeof(int) * hsizes.size(), hipMemcpyDeviceToHost, q));
@@ -1258,7 +1278,7 @@ struct LoamPipe {
             t0 = clk::now();
             hipLaunchKernelGGL(lm_insert_kernel, dim3(nseg), dim3(SBLOCK), lds_keys, q, S, dims, B, d_sizes.p, d_mtr2.p,
                                d_iters.p, d_rows.p, d_step_lm, d_step_it, d_status.p, lm_counting() ? 1 : 0);
-            hipLaunchKernelGGL(lm_filter_kernel, dim3(MAXVALID, nseg * 2), dim3(SBLOCK), lds_keys, q, S, dims, B, d_status.p);
+            hipLaunchKernelGGL(lm_filter_kernel, dim3(MAXVALID, nseg * 2), dim3(SBLOCK), lm_lds, q, S, dims, B, d_status.p);
             hipLaunchKernelGGL(lm_rebuild_kernel, dim3(nseg * 2), dim3(SBLOCK), 0, q, S, dims, B, d_status.p);
             hipLaunchKernelGGL(lm_flip_kernel, dim3(div_up(nseg, 64)), dim3(64), 0, q, S, nseg);
             GPSCAL_HIP(ctx, hipGetLastError());
