@@ -310,7 +310,7 @@ __global__ __launch_bounds__(SBLOCK) void lm_prepare_kernel(const PrepDesc *__re
     extern __shared__ unsigned long long dyn_lds[];
     __shared__ BlockShared S;
     __shared__ float tTobe[6];
-    __shared__ int s_shift[3], s_reset, s_valid[MAXVALID], s_nvalid, s_voff[2][MAXVALID + 1], s_cnt, s_center[6];
+    __shared__ int s_shift[3], s_reset, s_valid[MAXVALID], s_vstart[MAXVALID], s_nvalid, s_voff[2][MAXVALID + 1], s_cnt, s_center[6];
     __shared__ float s_pY[3];
     const int s = blockIdx.x;
     const PrepDesc D = descs[s];
@@ -445,14 +445,24 @@ __global__ __launch_bounds__(SBLOCK) void lm_prepare_kernel(const PrepDesc *__re
         s_voff[type][nvalid] = acc;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the copy is spread over the workgroup by POINT, not by cube (a wave per cube left the largest cube -- 20 k
+    // points of a street's ground -- to one wave: most of this kernel's 0.5 ms): the cube of an output slot by
+    // bisection of the offsets in LDS
     for (int type = 0; type < 2; ++type) {
-        const int *ts = B.tab_start[type][cur] + (long long)s * LNUM, *tc = B.tab_cnt[type][cur] + (long long)s * LNUM;
+        const int *ts = B.tab_start[type][cur] + (long long)s * LNUM;
         const float4 *pool = B.pool[type][cur] + (long long)s * dims.cap[type];
         float4 *dst = B.frommap[type] + (long long)s * dims.cap[type];
-        for (int k = wave; k < nvalid; k += SWAVES) {
-            const int c = s_valid[k], st0 = ts[c], cn = tc[c], o = s_voff[type][k];
-            for (int i = lane; i < cn; i += 64) dst[o + i] = pool[st0 + i];
+        __syncthreads();
+        if (threadIdx.x < nvalid) s_vstart[threadIdx.x] = ts[s_valid[threadIdx.x]];
+        __syncthreads();
+        const int total = s_voff[type][nvalid];
+        for (int i = threadIdx.x; i < total; i += SBLOCK) {
+            int lo = 0, hi = nvalid;  // last k with s_voff[k] <= i
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_voff[type][mid] <= i) lo = mid; else hi = mid;
+            }
+            dst[i] = pool[s_vstart[lo] + (i - s_voff[type][lo])];
         }
     }
     // ---- stack: last clouds -> map frame -> back (LM:466-478, 723-731), then VoxelGrid 0.2 / 0.4
@@ -507,7 +517,7 @@ __global__ __launch_bounds__(SBLOCK) void lm_insert_kernel(SegState *__restrict_
 {
     extern __shared__ unsigned long long dyn_lds[];
     __shared__ float tTobe[6];
-    __shared__ int s_voff[MAXVALID + 1];
+    __shared__ int s_voff[MAXVALID + 1], s_oc[MAXVALID], s_st0[MAXVALID], s_nn[MAXVALID], s_n0[MAXVALID];
     // counting sort of the new points by cube (see below)
     constexpr int DMAX = 64;
     __shared__ unsigned s_seen[(LNUM + 31) / 32];
@@ -676,24 +686,37 @@ __global__ __launch_bounds__(SBLOCK) void lm_insert_kernel(SegState *__restrict_
         const int *ts = B.tab_start[type][cur] + (long long)s * LNUM, *tc = B.tab_cnt[type][cur] + (long long)s * LNUM;
         const long long vcap = (long long)dims.cap[type] + dims.stack_cap[type];
         int *voff = B.vin_off[type] + (long long)s * MAXVALID, *vcnt = B.vin_cnt[type] + (long long)s * MAXVALID;
+        if (threadIdx.x < nvalid) {  // the cubes' old and new runs, for the copy below
+            const int c = G.valid[threadIdx.x];
+            s_oc[threadIdx.x] = tc[c];
+            s_st0[threadIdx.x] = ts[c];
+            s_nn[threadIdx.x] = nc[c];
+            s_n0[threadIdx.x] = ns[c];
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
             int acc = 0;
             for (int k = 0; k < nvalid; ++k) {
-                const int c = G.valid[k];
                 s_voff[k] = acc;
                 voff[k] = acc;
-                vcnt[k] = tc[c] + nc[c];
-                acc += tc[c] + nc[c];
+                vcnt[k] = s_oc[k] + s_nn[k];
+                acc += s_oc[k] + s_nn[k];
             }
             s_voff[nvalid] = acc;
         }
         __syncthreads();
         const float4 *pool = B.pool[type][cur] + (long long)s * dims.cap[type];
         float4 *vin = B.vin[type] + (long long)s * vcap;
-        for (int k = wave; k < nvalid; k += SWAVES) {
-            const int c = G.valid[k], o = s_voff[k], oc = tc[c], st0 = ts[c], nn = nc[c], n0 = ns[c];
-            for (int i = lane; i < oc; i += 64) vin[o + i] = pool[st0 + i];
-            for (int i = lane; i < nn; i += 64) vin[o + oc + i] = newq[n0 + i];
+        // by point over the whole workgroup (the cube of a slot by bisection), not a wave per cube: see lm_prepare_kernel
+        const int vtotal = s_voff[nvalid];
+        for (int i = threadIdx.x; i < vtotal; i += SBLOCK) {
+            int lo = 0, hi = nvalid;  // last k with s_voff[k] <= i
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_voff[mid] <= i) lo = mid; else hi = mid;
+            }
+            const int j = i - s_voff[lo];
+            vin[i] = j < s_oc[lo] ? pool[s_st0[lo] + j] : newq[s_n0[lo] + (j - s_oc[lo])];
         }
         __syncthreads();
     }
