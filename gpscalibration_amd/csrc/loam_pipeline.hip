@@ -756,6 +756,7 @@ __global__ __launch_bounds__(SBLOCK) void lm_rebuild_kernel(SegState *__restrict
     __shared__ short kmap[LNUM];
     __shared__ int s_part[SBLOCK];
     __shared__ int s_total;
+    __shared__ int s_ts2[LNUM + 1];  // the new table's starts (the bisection of the copy below)
     const int s = blockIdx.x >> 1, type = blockIdx.x & 1;
     const SegState &G = st[s];
     if (!G.active) return;
@@ -803,28 +804,35 @@ __global__ __launch_bounds__(SBLOCK) void lm_rebuild_kernel(SegState *__restrict
         if (c < LNUM) {
             ts2[c] = run;
             tc2[c] = loc[u];
+            s_ts2[c] = run;
             run += loc[u];
         }
     }
+    if (threadIdx.x == 0) s_ts2[LNUM] = s_total;
     __syncthreads();
     const float4 *pool = B.pool[type][cur] + (long long)s * dims.cap[type];
     float4 *pool2 = B.pool[type][nxt] + (long long)s * dims.cap[type];
     const float4 *newq = B.newq[type] + (long long)s * dims.stack_cap[type];
     const float4 *vout = B.vout[type] + (long long)s * vcap;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = wave; c < LNUM; c += SWAVES) {
-        const int cn = tc2[c];
-        if (cn == 0) continue;
-        const int o = ts2[c];
-        const int k = kmap[c];
-        if (k >= 0) {
-            const int vo = voff[k];
-            for (int i = lane; i < cn; i += 64) pool2[o + i] = vout[vo + i];
-        } else {
-            const int oc = tc[c], st0 = ts[c], n0 = ns[c];
-            for (int i = lane; i < oc; i += 64) pool2[o + i] = pool[st0 + i];
-            for (int i = lane; i < cn - oc; i += 64) pool2[o + oc + i] = newq[n0 + i];
+    // The new pool, by point over the whole workgroup: the cube of a slot by bisection of the new table's starts in
+    // LDS.  (A wave per cube walked 600 cubes per wave behind a dependent load of each count, and left the largest
+    // cube to one wave.)
+    const int total = s_total;
+    for (int i = threadIdx.x; i < total; i += SBLOCK) {
+        int lo = 0, hi = LNUM;  // last c with s_ts2[c] <= i: empty cubes before it share its start
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_ts2[mid] <= i) lo = mid; else hi = mid;
         }
+        const int c = lo, j = i - s_ts2[c], k = kmap[c];
+        float4 v;
+        if (k >= 0) {
+            v = vout[voff[k] + j];
+        } else {
+            const int oc = tc[c];
+            v = j < oc ? pool[ts[c] + j] : newq[ns[c] + (j - oc)];
+        }
+        pool2[i] = v;
     }
 }
 
