@@ -302,6 +302,9 @@ struct PrepDesc {
 // larger clouds took the HBM path of block_bitonic_sort -- ~100 passes of one workgroup over global memory,
 // 0.6 ms (`lm_prepare_kernel`) and 0.85 ms (`lm_filter_kernel`) per mapping step of the bench's bag -> KML run.
 constexpr int LM_LDS_KEYS = 16384;
+#ifndef GPSCAL_LM_DIAG
+#define GPSCAL_LM_DIAG 0  // timing experiments only (wrong results): 1 = lm_prepare without its VoxelGrid filters
+#endif
 __global__ __launch_bounds__(SBLOCK) void lm_prepare_kernel(const PrepDesc *__restrict__ descs, SegState *__restrict__ st,
                                                             PipeDims dims, PipeBufs B, const float4 *__restrict__ clast,
                                                             const float4 *__restrict__ slast, int *__restrict__ sizes,
@@ -474,9 +477,13 @@ __global__ __launch_bounds__(SBLOCK) void lm_prepare_kernel(const PrepDesc *__re
         for (int i = threadIdx.x; i < n; i += SBLOCK) s2[i] = dev_to_be_mapped(g, dev_to_map(g, src[i]));
         if (threadIdx.x == 0) s_cnt = 0;
         __syncthreads();
+#if GPSCAL_LM_DIAG & 1
+        if (threadIdx.x == 0) s_cnt = min(n, 64);
+#else
         block_voxel_grid(S, s2, n, type == 0 ? 0.2f : 0.4f, B.stack[type] + (long long)s * dims.stack_cap[type],
                          dims.stack_cap[type], &s_cnt, dyn_lds, B.keys[type] + (long long)s * dims.key_cap[type],
                          dims.key_cap[type], LM_LDS_KEYS);
+#endif
         __syncthreads();
         if (threadIdx.x == 0) sizes[4 * s + 2 + type] = s_cnt;
         __syncthreads();
