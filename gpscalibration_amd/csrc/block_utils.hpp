@@ -245,18 +245,19 @@ __device__ inline void block_voxel_grid(BlockShared &S, const float4 *__restrict
     }
     int np2 = next_pow2(n);
     // `lds_cap`: keys the caller's LDS buffer holds (a kernel launched with more dynamic LDS sorts larger clouds there)
-    unsigned long long *K = np2 <= lds_cap ? lds_keys : g_keys;
     if (np2 > lds_cap && np2 > g_cap) {  // host sized the scratch from the input counts; cannot happen
         S.overflow = 1;
         return;
     }
     // above the LDS size, with room for a second key buffer: radix sort by the voxel number instead of the bitonic
     // network in global memory (no padding to a power of two then)
-    const bool radix_g = np2 > lds_cap && g_cap >= 2 * n;
+    // (also when the keys would fit the LDS buffer but leave no room for the counters: 105 network passes otherwise)
+    const bool radix_g = (np2 > lds_cap || (n > 1024 && n + 4096 > lds_cap && lds_cap > LDS_KEYS)) && g_cap >= 2 * n;
     // in LDS as well once the caller's buffer also holds the 32 KiB of counters behind the keys (second buffer: the
     // global scratch): ~6 sweeps over the keys against 91 / 105 passes of the network at 8 192 / 16 384 keys
     const bool radix_l = !radix_g && np2 <= lds_cap && n > 1024 && n + 4096 <= lds_cap && g_cap >= n;
     const bool radix = radix_g || radix_l;
+    unsigned long long *K = np2 <= lds_cap && !radix_g ? lds_keys : g_keys;
     if (radix) np2 = n;
     for (int i = threadIdx.x; i < np2; i += SBLOCK) {
         unsigned long long key = ~0ull;

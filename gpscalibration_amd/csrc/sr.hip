@@ -630,7 +630,8 @@ int scan_registration_device(gpscal_ctx *ctx, int nsweeps, const int *xyz_off, c
         if (D.n_in < 0 || D.lf_cap < 0) return fail(ctx, GPSCAL_EINVAL, "scan registration: bad offsets");
         int np2 = 1;
         while (np2 < D.n_in) np2 <<= 1;
-        D.key_cap = np2 > LDS_KEYS ? np2 : 0;  // sectors above LDS_KEYS points sort in HBM
+        // sectors above LDS_KEYS points sort in HBM; twice the points: block_voxel_grid's radix sort wants a second buffer
+        D.key_cap = np2 > LDS_KEYS ? std::max(np2, 2 * D.n_in) : 0;
         D.key_off = key_total;
         D.pad = 0;
         key_total += D.key_cap;
@@ -725,7 +726,7 @@ extern "C" int gpscal_voxel_grid_batched(gpscal_ctx *ctx, int nclouds, const flo
         if (D.n < 0) return fail(ctx, GPSCAL_EINVAL, "gpscal_voxel_grid_batched: bad offsets");
         int np2 = 1;
         while (np2 < D.n) np2 <<= 1;
-        D.key_cap = np2 > LDS_KEYS ? np2 : 0;
+        D.key_cap = np2 > LDS_KEYS ? std::max(np2, 2 * D.n) : 0;  // room for the radix sort's second buffer
         D.key_off = key_total;
         key_total += D.key_cap;
     }
