@@ -99,6 +99,17 @@ def test_voxel_grid_matches_oracle(ctx, raw):
             assert rc == 0
             assert g.shape == ref.shape and np.array_equal(g, ref)
     assert len(got[1]) < len(clouds[1]) // 3
+    # the radix-sort path (key sets above the LDS window) with non-finite points in it, and a cloud of two sweeps
+    holes = full[1].copy()
+    holes[::97, 0] = np.nan
+    holes[5::211, 2] = np.inf
+    two = np.concatenate([full[0], full[1] + np.float32(0.05)])
+    for leaf in (0.2, 0.4):
+        got = ctx.voxel_grid([holes, two], leaf)
+        for c, g in zip([holes, two], got):
+            ref, rc = O.voxel_grid(c, leaf)
+            assert rc == 0
+            assert g.shape == ref.shape and np.array_equal(g, ref)
     # a single point, and leaves larger than the cloud (a voxel boundary still runs through the origin)
     rng = np.random.default_rng(2)
     odd = [rng.normal(0, 1, (1, 4)).astype(np.float32), rng.normal(0, 5, (5000, 4)).astype(np.float32)]
