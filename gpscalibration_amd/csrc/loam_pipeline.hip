@@ -953,18 +953,13 @@ struct LoamPipe {
         h_stamps = stamps;
         hipStream_t q = ctx->stream;
         {
-            // more than the default 64 KiB of dynamic LDS needs the attribute (per process, any thread)
-            static std::once_flag lds_once;
-            static hipError_t lds_err = hipSuccess;
-            std::call_once(lds_once, [] {
-                const int bytes = (int)(sizeof(unsigned long long) * LM_LDS_KEYS);
-                lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_prepare_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-                if (lds_err == hipSuccess)
-                    lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_filter_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            });
-            GPSCAL_HIP(ctx, lds_err);
+            // more than the default 64 KiB of dynamic LDS needs the attribute; set per run (it belongs to the current
+            // device's copy of the kernel: a process with contexts on several GPUs needs it on each)
+            const int bytes = (int)(sizeof(unsigned long long) * LM_LDS_KEYS);
+            GPSCAL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(lm_prepare_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            GPSCAL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(lm_filter_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         }
         const size_t npts = (size_t)std::max(sweep_off[nsw], 1);
         GPSCAL_HIP(ctx, a_xyz.bind(ctx, xyz, npts * 3));
