@@ -412,6 +412,52 @@ def test_voxel_grid_oracle_is_a_centroid_filter():
     assert rc == 1 and np.array_equal(out, far)
 
 
+def test_voxel_grid_of_a_growing_map_is_a_merge():
+    """pcl::VoxelGrid re-applied to (its own output + new points), as laserMapping does per map cube (LM:1044-1078):
+    the old part is one centroid per voxel in voxel order, so the filter equals a stable merge of it with the sorted
+    new points -- the property an incremental device filter may rely on (checked against the full filter here)."""
+    from gpscalibration_amd import synth
+    W = synth.lidar_world(0, length=200.0)
+    sw, _, truth = synth.drive(W, 7, seed=40, n_az=450, start=(0.0, 0.0))
+    leaf = np.float32(0.4)
+    inv = np.float32(1.0) / leaf
+    old = np.zeros((0, 4), dtype=np.float32)
+    for t, s in enumerate(sw):
+        new = O.sr_extract(s)["less_flat"].copy()[::2]
+        new[:, :3] += np.float32(truth[t, :3])
+        cloud = np.concatenate([old, new]).astype(np.float32)
+        ref, rc = O.voxel_grid(cloud, float(leaf))
+        assert rc == 0
+        if len(old):
+            lo, hi = cloud[:, :3].min(0), cloud[:, :3].max(0)
+            minb = np.floor(lo * inv).astype(np.int64)
+            div = np.floor(hi * inv).astype(np.int64) - minb + 1
+
+            def keys(p):
+                ijk = (np.floor(p[:, :3] * inv) - minb.astype(np.float32)).astype(np.int64)
+                return ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
+
+            ko, kn = keys(old), keys(new)
+            assert (np.diff(ko) > 0).all()  # sorted, one point per voxel
+            order = np.argsort(kn, kind="stable")
+            allk = np.concatenate([ko, kn[order]])
+            allp = np.concatenate([old, new[order]])
+            side = np.concatenate([np.zeros(len(ko), np.int8), np.ones(len(kn), np.int8)])
+            idx = np.lexsort((np.arange(len(allk)), side, allk))  # old before new inside a voxel, new in input order
+            allk, allp = allk[idx], allp[idx]
+            starts = np.flatnonzero(np.r_[True, np.diff(allk) != 0])
+            ends = np.r_[starts[1:], len(allk)]
+            got = np.empty((len(starts), 4), np.float32)
+            for r, (a, b) in enumerate(zip(starts, ends)):
+                acc = np.zeros(4, np.float32)
+                for e in range(a, b):
+                    acc = (acc + allp[e]).astype(np.float32)
+                got[r] = acc / np.float32(b - a)
+            assert got.shape == ref.shape and np.array_equal(got, ref), t
+        old = ref
+    assert len(old) > 2000
+
+
 def test_input_data_oracle_cuts_tracks_by_distance():
     """input_data.cpp:78-124, 266-444 restated around the node chain: tracks are cut when the travelled
     distance exceeds the segment length, the next one restarts after the last sample within
