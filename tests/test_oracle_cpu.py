@@ -458,6 +458,52 @@ def test_voxel_grid_of_a_growing_map_is_a_merge():
     assert len(old) > 2000
 
 
+def test_certificates_with_a_second_neighbour_list_and_packed_radii():
+    """The step kernel's certificates (a query closer than half of D1 / D5 to last iteration's
+    neighbour q0 has its nearest neighbour at q0 / among q0 and its 4 nearest) extended by a second list of four
+    (half of D9), with the three squared radii packed into the 32 bits the warm stream has today: 16 truncated bits
+    of r_a^2 and two 8-bit log2 ratios rounded down.  The decoded radii never exceed the exact ones, and every tier
+    returns the exact neighbour (k-d tree of scipy as the judge)."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(5)
+    m = 6000
+    tgt = np.r_[np.c_[rng.uniform(-10, 10, (m // 2, 2)), rng.normal(0, 0.01, m // 2)],
+                np.c_[rng.uniform(-10, 10, m // 2), 5.0 + rng.normal(0, 0.01, m // 2), rng.uniform(0, 4, m // 2)]]
+    tgt = tgt.astype(np.float32)
+    tree = cKDTree(tgt.astype(np.float64))
+    dk, ik = tree.query(tgt.astype(np.float64), k=10)
+    r2 = [(np.float32(0.25 * 0.99) * dk[:, k].astype(np.float32) ** 2).astype(np.float32) for k in (1, 5, 9)]
+    ra_bits = r2[0].view(np.uint32) & np.uint32(0xffff0000)
+
+    def enc(x):
+        ratio = np.maximum(x.astype(np.float64) / np.maximum(r2[0].astype(np.float64), 1e-300), 1.0)
+        return np.clip(np.floor(np.log2(ratio) * 32.0 - 0.01), 0, 255).astype(np.uint32)
+
+    word = ra_bits | (enc(r2[1]) << np.uint32(8)) | enc(r2[2])
+    ra = (word & np.uint32(0xffff0000)).view(np.float32)
+    rb = (ra * np.exp2(((word >> np.uint32(8)) & np.uint32(0xff)).astype(np.float32) / np.float32(32))).astype(np.float32)
+    rc = (ra * np.exp2((word & np.uint32(0xff)).astype(np.float32) / np.float32(32))).astype(np.float32)
+    assert (ra <= r2[0]).all() and (rb <= r2[1]).all() and (rc <= r2[2]).all()
+    assert np.median(1 - np.sqrt(rc / r2[2])) < 0.02  # what the packing gives away
+
+    nq = 20000
+    q = (tgt[rng.integers(0, m, nq)] + rng.normal(0, 0.08, (nq, 3))).astype(np.float32)
+    _, q0 = tree.query((q + rng.normal(0, 0.05, q.shape)).astype(np.float64))
+    dtrue, _ = tree.query(q.astype(np.float64))
+    d0 = ((q - tgt[q0]) ** 2).sum(1).astype(np.float32)
+    t1 = d0 < ra[q0]
+    t2 = ~t1 & (d0 < rb[q0])
+    t3 = ~t1 & ~t2 & (d0 < rc[q0])
+    assert t1.mean() > 0.1 and t2.mean() > 0.1 and t3.mean() > 0.05  # every tier is exercised
+
+    def nearest_of(cands):
+        dd = ((tgt[cands].astype(np.float64) - q[:, None, :].astype(np.float64)) ** 2).sum(2)
+        return np.sqrt(dd.min(1))
+
+    for msk, cands in ((t1, q0[:, None]), (t2, ik[q0][:, :5]), (t3, ik[q0][:, :9])):
+        np.testing.assert_allclose(nearest_of(cands)[msk], dtrue[msk], rtol=1e-9, atol=1e-12)
+
+
 def test_input_data_oracle_cuts_tracks_by_distance():
     """input_data.cpp:78-124, 266-444 restated around the node chain: tracks are cut when the travelled
     distance exceeds the segment length, the next one restarts after the last sample within
