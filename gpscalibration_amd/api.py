@@ -487,10 +487,12 @@ class ScanBatch:
         T0 = None if T0 is None else _f64(np.asarray(T0).reshape(self.npairs, 16))
         self.ctx._ck(self.ctx._L.gpscal_scan_batch_set_pose(self._h, _ptr(T0)), "scan_batch_set_pose")
 
-    def icp(self, iters, want_err=True, profile=False, T_out=None):
-        """Runs `iters` iterations.  Returns (T[npairs,4,4], mean_err[npairs,iters] | None, step_ms | None)."""
+    def icp(self, iters, want_err=True, profile=False, T_out=None, err_out=None):
+        """Runs `iters` iterations.  Returns (T[npairs,4,4], mean_err[npairs,iters] | None, step_ms | None).
+        `T_out` / `err_out` (float64, [npairs,4,4] / [npairs,iters]; host arrays or CUDA tensors) receive the poses and
+        the error history in place: with device tensors the call returns after enqueue."""
         T = T_out if T_out is not None else np.empty((self.npairs, 4, 4))
-        err = np.empty((self.npairs, iters)) if want_err else None
+        err = err_out if err_out is not None else (np.empty((self.npairs, iters)) if want_err else None)
         ms = np.empty(iters, dtype=np.float32) if profile else None
         self.ctx._ck(self.ctx._L.gpscal_scan_batch_icp(self._h, iters, _ptr(T), _ptr(err), _ptr(ms)),
                      "scan_batch_icp")

@@ -249,8 +249,11 @@ extern "C" int gpscal_allgather_chains(gpscal_ctx *ctx, const double *local, con
         if (rc == 0) rc = rc2;
     }
     if (rc != 0) return fail(ctx, GPSCAL_ECOMM, r->err ? r->err(rc) : "RCCL collective failed");
-    bool sync = true;
+    // device pointers in and out: the call returns after enqueue on the context's stream, like every other entry point
+    // (gpscal_wait_for_stream / gpscal_make_stream_wait order it against the caller's streams).  A staged input must
+    // outlive the collective and a host output must be complete on return: only then does the host wait.
+    bool sync = in.tmp.p != nullptr;
     GPSCAL_HIP(ctx, out.commit(ctx, &sync));
-    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (sync) GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GPSCAL_OK;
 }

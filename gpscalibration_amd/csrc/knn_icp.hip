@@ -385,12 +385,12 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
 // retires with its slowest wave: in the search-heavy iterations the waves of one workgroup differ a lot); with
 // single-wave workgroups the kernel itself is fastest (launch times 346 ... 47 us against 385 ... 49 us for 256
 // threads) but four concurrent chains of 16 384-workgroup launches then cost more than they hide.
-#ifndef GPSCAL_STEP_BLOCK
-#define GPSCAL_STEP_BLOCK 128  // measured at 64 x 65 536 points, 4 chains: 64 / 128 / 256 threads = 728 / 775 / 746 k iterations/s
-#endif
-constexpr int STEP_BLOCK = GPSCAL_STEP_BLOCK;
+// Both sizes are compiled; the batch picks one (batch_setup_sources): 128 threads for batches that fill the chip many
+// times over (measured at 64 x 65 536 points, 4 chains: 64 / 128 / 256 threads = 728 / 775 / 746 k iterations/s), 256
+// for small ones, where the launch is latency-bound and the solve kernel's sum over the workgroups' partial sums is
+// on the critical path (one 65 536-point pair: 33.4 k iterations/s with 128 threads, 35.8 k with 256).
 
-template <int QPT, bool WEIGHTED, bool BALL>
+template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK>
 __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
     const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
     const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
@@ -1020,6 +1020,7 @@ struct gpscal_scan_batch {
     long long total_n = 0;
     bool weighted = false;
     int qpt = 1, nblk = 0, diag = 0;
+    int step_block = 128;  // threads per workgroup of icp_step_kernel (128 or 256, by batch size)
     int uni_n = 0, uni_m = 0, uni_bpp = 0;  // equal-sized scans stored back to back: workgroup slices by arithmetic
     int ball_r = 0;  // block radius of the ball search (0 = fine -> coarse 3x3x3 search)
     DevBuf<PairDesc> pairs;  // target descs + source fields
@@ -1189,11 +1190,14 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
         if (cnt > 0 && hs / cnt < 0.25) B->ball_r = 4;
     }
     if (const char *e = getenv("GPSCAL_BALL_R")) B->ball_r = std::min(std::max(atoi(e), 0), 8);
+    // workgroup size of the step kernel: 256 threads while 128-thread workgroups would not fill the chip four times over
+    B->step_block = B->total_n >= 4ll * 128 * 8 * ctx->prop.multiProcessorCount ? 128 : 256;
+    if (const char *e = getenv("GPSCAL_STEP_BLOCK")) B->step_block = atoi(e) == 256 ? 256 : 128;
     std::vector<int> bp, bf;
     for (int b = 0; b < np; ++b) {
         PairDesc &P = B->hpairs[b];
         P.pblk_off = (int)bp.size();
-        int per = STEP_BLOCK * B->qpt;
+        int per = B->step_block * B->qpt;
         for (int f = 0; f < P.n; f += per) {
             bp.push_back(b);
             bf.push_back(f);
@@ -1357,8 +1361,13 @@ static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st, 
     // c < 0: the whole batch in one launch (profiling mode: the launch the roofline is quoted for)
     const int b0 = c < 0 ? 0 : B->chain_blk[c], nb = (c < 0 ? B->nblk : B->chain_blk[c + 1]) - b0;
     if (nb <= 0) return;
-#define STEP(QPT, W, BALL)                                                                                        \
-    hipLaunchKernelGGL((icp_step_kernel<QPT, W, BALL>), dim3(nb), dim3(STEP_BLOCK), 0, st, B->pairs.p, B->blk_pair.p + b0, \
+#define STEP(QPT, W, BALL)                                      \
+    do {                                                        \
+        if (B->step_block == 256) STEP_BS(QPT, W, BALL, 256);   \
+        else STEP_BS(QPT, W, BALL, 128);                        \
+    } while (0)
+#define STEP_BS(QPT, W, BALL, BS)                                                                                        \
+    hipLaunchKernelGGL((icp_step_kernel<QPT, W, BALL, BS>), dim3(nb), dim3(BS), 0, st, B->pairs.p, B->blk_pair.p + b0, \
                        B->blk_first.p + b0, B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p, G.cell_start,   \
                        B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p,                              \
                        B->partials.p + (size_t)b0 * (B->weighted ? NACC_WEIGHTED : NACC_PLAIN), nb,                  \
@@ -1373,6 +1382,7 @@ static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st, 
         if (B->qpt == 4) STEP(4, false, false); else if (ball) STEP(1, false, true); else STEP(1, false, false);
     }
 #undef STEP
+#undef STEP_BS
 }
 
 static void launch_solve(gpscal_scan_batch *B, int it, int c, hipStream_t st)

@@ -378,7 +378,8 @@ int gpscal_comm_unique_id(void *id_bytes);
 int gpscal_comm_init(gpscal_ctx *ctx, const void *id_bytes, int rank,
                      int world);
 /* local: count doubles on this rank; counts: world ints (doubles per rank);
- * all: sum(counts) doubles, rank-major.  Pointers host or device. */
+ * all: sum(counts) doubles, rank-major.  Pointers host or device; with device
+ * pointers for both the call returns after enqueue on the context's stream. */
 int gpscal_allgather_chains(gpscal_ctx *ctx, const double *local,
                             const int *counts, double *all);
 int gpscal_comm_destroy(gpscal_ctx *ctx);

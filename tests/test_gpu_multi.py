@@ -118,6 +118,15 @@ def test_rccl_allgather_chains_ragged_path_world_of_one(monkeypatch):
     except GpscalError as e:
         ctx.close()
         pytest.skip("RCCL not usable here: %s" % e)
+    try:
+        _rccl_world_of_one_body(ctx, monkeypatch)
+    finally:
+        ctx.comm_destroy()
+        ctx.close()
+
+
+def _rccl_world_of_one_body(ctx, monkeypatch):
+    from gpscalibration_amd import GpscalError
     rng = np.random.default_rng(3)
     for force in (False, True):
         if force:
@@ -136,8 +145,29 @@ def test_rccl_allgather_chains_ragged_path_world_of_one(monkeypatch):
     assert torch.equal(d_in, d_out)
     with pytest.raises(GpscalError):  # NULL local with a non-zero count
         ctx._ck(ctx._L.gpscal_allgather_chains(ctx._h, None, _ptr(cnt), _ptr(d_out)), "allgather null")
-    ctx.comm_destroy()
-    ctx.close()
+    # device pointers in and out: the gather is enqueued behind whatever the context's stream holds and the call
+    # returns without waiting for it (host pointers make it wait, as everywhere in the ABI)
+    import time
+    from gpscalibration_amd import synth
+    npairs = 24
+    tg, to, sr, so, _ = synth.scan_batch(npairs, 65536)
+    sb = ctx.scan_batch(torch.from_numpy(tg).cuda(), to, torch.from_numpy(sr).cuda(), so)
+    d_T = torch.empty((npairs, 4, 4), dtype=torch.float64, device="cuda")
+    d_all = torch.empty((npairs, 4, 4), dtype=torch.float64, device="cuda")
+    cnts = np.array([16 * npairs], dtype=np.int32)
+    sb.icp(50, want_err=False, T_out=d_T)  # warm-up: graph capture
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(16):  # ~20 ms of queued work (16 graph replays of 24 x 50 iterations) behind ~2 ms of host calls ...
+        sb.icp(50, want_err=False, T_out=d_T)  # (no set_pose here: a host pose makes that call wait for the stream)
+    ctx._ck(ctx._L.gpscal_allgather_chains(ctx._h, _ptr(d_T), _ptr(cnts), _ptr(d_all)), "allgather behind work")
+    t_call = time.perf_counter() - t0
+    ctx.sync()
+    t_all = time.perf_counter() - t0
+    assert t_call < 0.6 * t_all, (t_call, t_all)  # ... which the gather did not wait for
+    torch.cuda.synchronize()
+    assert torch.equal(d_T, d_all)
+    sb.close()
 
 
 _COEXIST = r'''

@@ -540,6 +540,98 @@ def test_icp_run_in_two_calls_equals_one_call(ctx):
     two.close()
 
 
+def _ragged_batch(npairs, n):
+    """Pairs of different sizes, a tiny source and a tiny target among them, stored back to back."""
+    tg, to, sr, so, _ = synth.scan_batch(npairs, n)
+    rng = np.random.default_rng(77)
+    tgts, srcs = [], []
+    for p in range(npairs):
+        t, s = tg[to[p]:to[p + 1]], sr[so[p]:so[p + 1]]
+        if p == 3:
+            s = s[:5]            # a source of five points
+        elif p == 5:
+            t = t[::9]           # a sparse target
+        elif p == 7:
+            s = s[:1]
+        else:
+            s = s[: int(rng.integers(n // 3, n))]
+            t = t[: int(rng.integers(n // 2, n))]
+        tgts.append(t)
+        srcs.append(s)
+    to2 = np.cumsum([0] + [len(t) for t in tgts]).astype(np.int64)
+    so2 = np.cumsum([0] + [len(s) for s in srcs]).astype(np.int64)
+    return np.concatenate(tgts), to2, np.concatenate(srcs), so2
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_icp_graph_chains_and_slices_agree_with_each_other_and_the_oracle(ctx, monkeypatch, ragged):
+    """What the headline benchmark runs -- the captured graph with several step -> solve chains, chain-local block
+    and partial-sum offsets, workgroup slices by arithmetic -- against the whole-batch launches of the profiling mode,
+    against one chain, against the table-driven slices and against both workgroup sizes of the step kernel, bit for
+    bit; and against the kd-tree oracle.  12 pairs: two chains by default, four forced; the ragged batch has a
+    five-point and a one-point source and a sparse target, so chains split unevenly and slices come from the table."""
+    npairs, n, iters = 12, 4096, 12
+    if ragged:
+        tg, to, sr, so = _ragged_batch(npairs, n)
+    else:
+        tg, to, sr, so, _ = synth.scan_batch(npairs, n)
+    variants = {"default": {}, "chains1": {"GPSCAL_ICP_CHAINS": "1"}, "chains4": {"GPSCAL_ICP_CHAINS": "4"},
+                "table": {"GPSCAL_ICP_UNIFORM": "0"}, "wg128": {"GPSCAL_STEP_BLOCK": "128", "GPSCAL_ICP_CHAINS": "4"}}
+    runs = {}
+    for name, env in variants.items():
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sb = ctx.scan_batch(tg, to, sr, so)
+        for k in env:
+            monkeypatch.delenv(k)
+        T, err, _ = sb.icp(iters)                 # the replayed graph
+        idx, sqd = sb.correspondences()
+        sb.set_pose(None)
+        Tp, errp, _ = sb.icp(iters, profile=True)  # whole-batch launches, one stream
+        assert np.array_equal(T, Tp) and np.array_equal(err, errp), name
+        runs[name] = (T.copy(), err.copy(), idx, sqd)
+        if name == "default":
+            sb.set_pose(None)
+            T_prev, _, _ = sb.icp(iters - 1)
+        sb.close()
+    for name in ("chains1", "chains4", "table"):
+        assert all(np.array_equal(a, b) for a, b in zip(runs["default"], runs[name])), name
+    # another workgroup size adds the float64 sums in another order: last bits of the pose, never a correspondence
+    assert np.abs(runs["wg128"][0] - runs["default"][0]).max() < 1e-9
+    assert np.array_equal(runs["wg128"][2], runs["default"][2]) and np.array_equal(runs["wg128"][3], runs["default"][3])
+    T, err, idx, sqd = runs["default"]
+    for p in range(npairs):
+        t, s = tg[to[p]:to[p + 1]], sr[so[p]:so[p + 1]]
+        kd = O.KdTree(t)
+        if len(s) >= 3:
+            T_ref, hist = kd.icp_run(s, iters)
+            assert np.abs(T[p] - T_ref).max() < 1e-5 and np.abs(err[p] - hist).max() < 1e-5, p
+        ridx, rsqd = O.knn_brute(t, O.transform_f32(T_prev[p], s), 1)
+        assert np.array_equal(idx[so[p]:so[p + 1]], ridx[:, 0]) and np.array_equal(sqd[so[p]:so[p + 1]], rsqd[:, 0]), p
+
+
+@pytest.mark.parametrize("npairs,n,iters", [(8, 262144, 20), (4, 1048576, 10)])
+def test_icp_batches_at_the_benchmark_shapes_match_oracle(ctx, npairs, n, iters):
+    """Many-pair batches at the sizes of BASELINE configs[3] / [4] through ONE scan batch (the index of such a batch
+    is gigabytes, several chains run in the graph): every pair's pose and error history against the kd-tree oracle,
+    and a sample of every pair's last-iteration correspondences bit-exact against brute force."""
+    tg, to, sr, so, T_true = synth.scan_batch(npairs, n)
+    sb = ctx.scan_batch(tg, to, sr, so)
+    T, err, _ = sb.icp(iters)
+    idx, sqd = sb.correspondences()
+    sb.set_pose(None)
+    T_prev, _, _ = sb.icp(iters - 1)
+    sb.close()
+    rng = np.random.default_rng(n)
+    for p in range(npairs):
+        t, s = tg[to[p]:to[p + 1]], sr[so[p]:so[p + 1]]
+        T_ref, hist = O.KdTree(t).icp_run(s, iters)
+        assert np.abs(T[p] - T_ref).max() < 1e-5 and np.abs(err[p] - hist).max() < 1e-5, p
+        sel = rng.choice(n, 600, replace=False)
+        ridx, rsqd = O.knn_brute(t, O.transform_f32(T_prev[p], s[sel]), 1)
+        assert np.array_equal(idx[so[p] + sel], ridx[:, 0]) and np.array_equal(sqd[so[p] + sel], rsqd[:, 0]), p
+
+
 # -------------------------------------------------------------------- track
 def _segments(nseg, poses, seed, dropout=0.0):
     d = synth.track_segments(nseg, poses, seed=seed, dropout=dropout)

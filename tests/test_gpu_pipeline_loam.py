@@ -5,7 +5,7 @@ transformMaintenance, gpscal_loam_run_batched) against the lock-step CPU restate
 Parity bar: feature extraction is bit-exact (test_gpu_registration.py); the odometry / mapping
 loops agree to ~1e-4 per sweep (device libm, summation order); the poses are a sequential
 estimate, so these differences feed back through the map.  Over 30 sweeps (15 mapping cycles)
-the bar is 5e-3 rad / 2e-2 m on every intermediate pose and 2e-2 m on the /true_odometry_to_init
+the bar is 5e-4 rad / 2e-3 m on every intermediate pose (measured: 3.5e-4 m on the mapped poses) and 2e-3 m on the /true_odometry_to_init
 track.  Parity unpinned against the reference itself (PCL / OpenCV / tf absent, no fixtures)."""
 import numpy as np
 import pytest
@@ -32,10 +32,10 @@ def _check(got, ref, n):
         g, r = got[key], ref[key]
         m = np.isfinite(r[:, 0])
         assert np.array_equal(np.isfinite(g[:, 0]), m), key
-        assert np.abs(g[m][:, :3] - r[m][:, :3]).max() < 5e-3, (key, "rot")
-        assert np.abs(g[m][:, 3:] - r[m][:, 3:]).max() < 2e-2, (key, "trans")
+        assert np.abs(g[m][:, :3] - r[m][:, :3]).max() < 5e-4, (key, "rot", np.abs(g[m][:, :3] - r[m][:, :3]).max())
+        assert np.abs(g[m][:, 3:] - r[m][:, 3:]).max() < 2e-3, (key, "trans", np.abs(g[m][:, 3:] - r[m][:, 3:]).max())
     assert np.all(np.isnan(got["track"][0])) and np.all(np.isnan(ref["track"][0]))
-    assert np.abs(got["track"][1:, :2] - ref["track"][1:, :2]).max() < 2e-2
+    assert np.abs(got["track"][1:, :2] - ref["track"][1:, :2]).max() < 2e-3
     assert np.array_equal(got["track"][1:, 2:], ref["track"][1:, 2:])  # HEIGHT and stamps are exact
 
 
@@ -117,7 +117,7 @@ def test_loam_run_ring_shift(ctx):
 def test_input_data_segmentation_matches_oracle(ctx):
     """input_data.cpp:78-124, 266-444: both passes of two bags, cut online from the device track.
     The cuts (first / last replayed message of every track) must equal the oracle's exactly; the
-    samples agree to 2e-2 m like the chain itself."""
+    samples agree to 2e-2 m (measured: 1.1e-2 m at the end of the longest replayed stretch, where the float32 odometry of two implementations has drifted apart over ~100 sweeps; the chain tests above hold 2e-3 m over 30 sweeps)."""
     W = synth.lidar_world(0, length=600.0)
     bag_a, st_a, _ = synth.drive(W, 70, seed=1, n_az=900)
     bag_b, st_b, _ = synth.drive(W, 40, seed=7, n_az=900, start=(200.0, -1.0), speed=6.0)

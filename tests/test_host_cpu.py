@@ -179,17 +179,21 @@ def _oracle_tracks(gprmc, longs, shorts, kml_original, kml_calibrated):
     return len(gps), len(acc)
 
 
-def test_bag_to_kml_orchestration_gloo_world2(tmp_path):
+@pytest.mark.parametrize("nb,poses", [(3, 2400), (7, 6000)])
+def test_bag_to_kml_orchestration_gloo_world2(tmp_path, nb, poses):
     """N > 1 path of bag -> KML (parallel.bag_to_kml_sharded): bags sharded in contiguous blocks, ONE ragged
     exchange of the segments' pose chains, global track alignment + KML on rank 0.  Two gloo ranks must write
     the files a single process writes, byte for byte (SLAM stand-in: precomputed chains; global stage: the
-    oracle -- there is no GPU here; tests/test_gpu_multi.py runs the same function with the product's stages)."""
+    oracle -- there is no GPU here; tests/test_gpu_multi.py runs the same function with the product's stages).
+    The second case is the strong-scaling shape of bench.py's bag -> KML section: a fixed total of bags, more of
+    them than ranks, split 4 + 3."""
     import pickle
     from gpscalibration_amd import synth
     from gpscalibration_amd.parallel import bag_to_kml_sharded
-    longs, shorts, gprmc = synth.segmented_run(2400, 600, 200, 60, seed=5, dropout=0.2)
-    nb = 3  # bags of unequal size: 1, 1 and the rest of the long segments; shorts by time span
-    cut = [longs[0][0, 3], longs[1][0, 3], longs[2][0, 3], np.inf]
+    longs, shorts, gprmc = synth.segmented_run(poses, 600, 200, 60, seed=5, dropout=0.2)
+    assert len(longs) >= nb
+    # bags of unequal size: one long segment each, the last takes the rest; shorts by time span
+    cut = [longs[b][0, 3] for b in range(nb)] + [np.inf]
     bags = []
     for b in range(nb):
         lg = [(k, t) for k, t in enumerate(longs) if cut[b] <= t[0, 3] < cut[b + 1]]

@@ -10,5 +10,5 @@ npairs, n, iters = 64, 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 50
 tg, to, sr, so, _ = synth.scan_batch(npairs, n)
 ctx = Context(0)
 sb = ctx.scan_batch(torch.from_numpy(tg).cuda(), to, torch.from_numpy(sr).cuda(), so)
-sb.icp(iters, want_err=False, profile=True)
+sb.icp(iters, want_err=True, profile=True)
 ctx.sync()
