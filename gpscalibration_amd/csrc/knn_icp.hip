@@ -390,41 +390,39 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
 // for small ones, where the launch is latency-bound and the solve kernel's sum over the workgroups' partial sums is
 // on the critical path (one 65 536-point pair: 33.4 k iterations/s with 128 threads, 35.8 k with 256).
 
+// The work of one workgroup of the step: its slice of the pair's grouped source (QPT batches of STEP_BLOCK points from
+// `first`) through transform, certificates and search; leaves every wave's sums in wsum[wave][0 .. NACC) (the caller
+// synchronises the workgroup and adds them).  T: the pair's float32 pose (12 values).  Shared by icp_step_kernel
+// (one launch per iteration) and icp_persistent_kernel (all iterations of small batches in one launch).
+struct StepArgs {
+    const float4 *__restrict__ src4;
+    const double *__restrict__ wsrc;
+    const float4 *__restrict__ sorted;
+    const float4 *__restrict__ nbr;
+    const float2 *__restrict__ pt_r2;
+    const unsigned *__restrict__ cell_start;
+    int *__restrict__ nn_idx;
+    float *__restrict__ nn_sqd;
+    float4 *__restrict__ warm_q;
+    unsigned *__restrict__ warm_r2;
+};
 template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK>
-__global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
-    const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
-    const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
-    const float4 *__restrict__ nbr, const float2 *__restrict__ pt_r2, const unsigned *__restrict__ cell_start,
-    const float *__restrict__ pose32, int *__restrict__ nn_idx, float *__restrict__ nn_sqd,
-    float4 *__restrict__ warm_q, unsigned *__restrict__ warm_r2, double *__restrict__ partials, int nblk, int diag,
-    int write_nn, int uni_n, int uni_m, int uni_bpp, int uni_pair0)
+__device__ __forceinline__ void step_body(const StepArgs &A, const PairDesc &P, const float *T, int first, int src_n,
+                                          long long src_off, long long tgt_off, int diag, int write_nn,
+                                          double (&wsum)[STEP_BLOCK / 64][WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN],
+                                          double (&tslab)[STEP_BLOCK / 64][8][64])
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
-    __shared__ double wsum[STEP_BLOCK / 64][NACC];
-    __shared__ double tslab[STEP_BLOCK / 64][8][64];  // per-wave transpose slab (4 KiB / wave)
-
-    const int lb = xcd_remap(blockIdx.x, nblk);
-    // A batch of equal-sized scans (uni_n > 0: every source cloud uni_n points, every target cloud uni_m, stored back
-    // to back) needs no table to find a workgroup's slice: two dependent scalar loads less in front of the streams,
-    // which is a fifth of a workgroup's life in the converged state.
-    int b, first, src_n;
-    long long src_off, tgt_off;
-    if (uni_n > 0) {
-        const int bl = lb / uni_bpp;
-        b = uni_pair0 + bl;
-        first = (lb - bl * uni_bpp) * (STEP_BLOCK * QPT);
-        src_n = uni_n;
-        src_off = (long long)b * uni_n;
-        tgt_off = (long long)b * uni_m;
-    } else {
-        b = __builtin_amdgcn_readfirstlane(blk_pair[lb]);
-        first = __builtin_amdgcn_readfirstlane(blk_first[lb]);
-        src_n = pairs[b].n;
-        src_off = pairs[b].src_off;
-        tgt_off = pairs[b].tgt_off;
-    }
-    const PairDesc &P = pairs[b];  // the grid levels: read by the search only
-    const float *T = pose32 + (size_t)b * 12;
+    const float4 *__restrict__ src4 = A.src4;
+    const double *__restrict__ wsrc = A.wsrc;
+    const float4 *__restrict__ sorted = A.sorted;
+    const float4 *__restrict__ nbr = A.nbr;
+    const float2 *__restrict__ pt_r2 = A.pt_r2;
+    const unsigned *__restrict__ cell_start = A.cell_start;
+    int *__restrict__ nn_idx = A.nn_idx;
+    float *__restrict__ nn_sqd = A.nn_sqd;
+    float4 *__restrict__ warm_q = A.warm_q;
+    unsigned *__restrict__ warm_r2 = A.warm_r2;
     const float r00 = T[0], r01 = T[1], r02 = T[2], tx = T[3];
     const float r10 = T[4], r11 = T[5], r12 = T[6], ty = T[7];
     const float r20 = T[8], r21 = T[9], r22 = T[10], tz = T[11];
@@ -550,6 +548,44 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
             __builtin_amdgcn_wave_barrier();
         }
     }
+}
+
+template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK>
+__global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
+    const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
+    const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
+    const float4 *__restrict__ nbr, const float2 *__restrict__ pt_r2, const unsigned *__restrict__ cell_start,
+    const float *__restrict__ pose32, int *__restrict__ nn_idx, float *__restrict__ nn_sqd,
+    float4 *__restrict__ warm_q, unsigned *__restrict__ warm_r2, double *__restrict__ partials, int nblk, int diag,
+    int write_nn, int uni_n, int uni_m, int uni_bpp, int uni_pair0)
+{
+    constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
+    __shared__ double wsum[STEP_BLOCK / 64][NACC];
+    __shared__ double tslab[STEP_BLOCK / 64][8][64];  // per-wave transpose slab (4 KiB / wave)
+
+    const int lb = xcd_remap(blockIdx.x, nblk);
+    // A batch of equal-sized scans (uni_n > 0: every source cloud uni_n points, every target cloud uni_m, stored back
+    // to back) needs no table to find a workgroup's slice: two dependent scalar loads less in front of the streams,
+    // which is a fifth of a workgroup's life in the converged state.
+    int b, first, src_n;
+    long long src_off, tgt_off;
+    if (uni_n > 0) {
+        const int bl = lb / uni_bpp;
+        b = uni_pair0 + bl;
+        first = (lb - bl * uni_bpp) * (STEP_BLOCK * QPT);
+        src_n = uni_n;
+        src_off = (long long)b * uni_n;
+        tgt_off = (long long)b * uni_m;
+    } else {
+        b = __builtin_amdgcn_readfirstlane(blk_pair[lb]);
+        first = __builtin_amdgcn_readfirstlane(blk_first[lb]);
+        src_n = pairs[b].n;
+        src_off = pairs[b].src_off;
+        tgt_off = pairs[b].tgt_off;
+    }
+    const StepArgs A = {src4, wsrc, sorted, nbr, pt_r2, cell_start, nn_idx, nn_sqd, warm_q, warm_r2};
+    step_body<QPT, WEIGHTED, BALL, STEP_BLOCK>(A, pairs[b], pose32 + (size_t)b * 12, first, src_n, src_off, tgt_off, diag,
+                                                write_nn, wsum, tslab);
     __syncthreads();
     if (threadIdx.x < NACC) {
         double v = 0.0;
@@ -559,34 +595,29 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
     }
 }
 
-// One wave per pair: reduce the pair's block partials in fixed order, solve the
-// rigid transform, compose the pose.  (TC:416-541 on 3-D data.)
-template <bool WEIGHTED>
-__global__ __launch_bounds__(64) void icp_solve_kernel(const PairDesc *__restrict__ pairs,
-                                                        const double *__restrict__ partials,
-                                                        double *__restrict__ pose64, float *__restrict__ pose32,
-                                                        double *__restrict__ err_hist, int it, int iters_cap, int pair0)
+// Agent-scope (sc1) loads and stores: data handed from one workgroup to another inside a launch
+// (icp_persistent_kernel) must not be served from, nor stay in, a CU's vector L1 (MI355X_MICROARCH.md, "Workgroup
+// dispatch, XCD placement & inter-workgroup visibility").
+template <class T>
+__device__ __forceinline__ T ld_agent(const T *p)
 {
-    constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
-    const int b = pair0 + blockIdx.x;
-    const PairDesc &P = pairs[b];
-    const int lane = threadIdx.x;
-    double a[NACC];
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) a[k] = 0.0;
-    for (int j = lane; j < P.pblk_cnt; j += 64) {
-        const double *pp = partials + (size_t)(P.pblk_off + j) * NACC;
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) a[k] += pp[k];
-    }
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) a[k] = wave_sum(a[k]);
-    if (lane != 0) return;  // wave_sum leaves the totals in every lane
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ void st_agent(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
+// From a pair's total sums to its new pose (TC:416-541 on 3-D data): one lane.  AGENT: the pose is read and written
+// with agent-scope accesses (the persistent kernel hands it from workgroup to workgroup).
+template <bool WEIGHTED, bool AGENT>
+__device__ __forceinline__ void solve_pose(const double (&a)[WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN], double *T,
+                                           float *pose32_b, double *err_slot)
+{
     const double sw = a[0];
-    double *T = pose64 + (size_t)b * 16;
     const double cnt = WEIGHTED ? a[24] : a[0];
-    if (err_hist) err_hist[(size_t)b * iters_cap + it] = cnt > 0.0 ? a[16] / cnt : 0.0;
+    if (err_slot) *err_slot = cnt > 0.0 ? a[16] / cnt : 0.0;
     if (!(sw > 0.0)) return;  // no correspondences: pose unchanged
     double cp[3] = {a[1] / sw, a[2] / sw, a[3] / sw};
     double cq[3] = {a[4] / sw, a[5] / sw, a[6] / sw};
@@ -612,20 +643,154 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const PairDesc *__restric
 #pragma unroll
     for (int r = 0; r < 3; ++r) t[r] = cq[r] - (R[3 * r] * cp[0] + R[3 * r + 1] * cp[1] + R[3 * r + 2] * cp[2]);
     // T <- [R|t] * T
-    double Tn[12];
+    double To[12], Tn[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) To[k] = AGENT ? ld_agent(T + k) : T[k];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            double v = R[3 * r] * T[c] + R[3 * r + 1] * T[4 + c] + R[3 * r + 2] * T[8 + c];
+            double v = R[3 * r] * To[c] + R[3 * r + 1] * To[4 + c] + R[3 * r + 2] * To[8 + c];
             if (c == 3) v += t[r];
             Tn[4 * r + c] = v;
         }
     }
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
-        T[k] = Tn[k];
-        pose32[(size_t)b * 12 + k] = (float)Tn[k];
+        if (AGENT) {
+            st_agent(T + k, Tn[k]);
+            st_agent(pose32_b + k, (float)Tn[k]);
+        } else {
+            T[k] = Tn[k];
+            pose32_b[k] = (float)Tn[k];
+        }
+    }
+}
+
+// One wave per pair: reduce the pair's block partials in fixed order, solve the
+// rigid transform, compose the pose.
+template <bool WEIGHTED>
+__global__ __launch_bounds__(64) void icp_solve_kernel(const PairDesc *__restrict__ pairs,
+                                                        const double *__restrict__ partials,
+                                                        double *__restrict__ pose64, float *__restrict__ pose32,
+                                                        double *__restrict__ err_hist, int it, int iters_cap, int pair0)
+{
+    constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
+    const int b = pair0 + blockIdx.x;
+    const PairDesc &P = pairs[b];
+    const int lane = threadIdx.x;
+    double a[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) a[k] = 0.0;
+    for (int j = lane; j < P.pblk_cnt; j += 64) {
+        const double *pp = partials + (size_t)(P.pblk_off + j) * NACC;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) a[k] += pp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) a[k] = wave_sum(a[k]);
+    if (lane != 0) return;  // wave_sum leaves the totals in every lane
+    solve_pose<WEIGHTED, false>(a, pose64 + (size_t)b * 16, pose32 + (size_t)b * 12,
+                                err_hist ? err_hist + (size_t)b * iters_cap + it : nullptr);
+}
+
+// ------------------------------------------------------------ all iterations of a small batch in one launch
+//
+// One 65 536-point pair is 2 MiB of compulsory traffic per iteration -- 0.26 us at HBM speed -- so a run of such a
+// pair is a chain of launch latencies (step ~20 us + solve ~9 us per iteration through the captured graph).  For
+// batches whose step grid fits the chip at once (every workgroup resident), the whole run is ONE launch:
+// per iteration a workgroup works its slice (step_body), stores its partial sums with agent-scope stores, drains
+// them and takes a ticket of its pair; the workgroup that draws the pair's last ticket of the iteration adds the
+// partial sums in the solve kernel's order, solves, stores the new pose (agent scope) and raises the pair's
+// generation; every workgroup of the pair polls the generation (one lane, agent-scope loads, s_sleep) and goes on.
+// Same sums in the same order as icp_step_kernel + icp_solve_kernel: bit-identical poses.  The hand-off is the
+// sc1 form of MI355X_MICROARCH.md's table (stores and loads of the handed-off bytes all agent scope, every storing
+// wave drained, one lane signals after the workgroup's barrier, the consumer loads after its own ticket returned /
+// its poll matched).  Every wait is bounded: a workgroup that polls longer than ~a second raises the pair's error
+// word and every workgroup leaves (the host reports GPSCAL_EHIP); the grid is only launched when all of it is
+// resident (2 workgroups per CU at most), so nothing waits for a workgroup that cannot start.
+struct IcpCtl {  // one 128-byte line per pair
+    unsigned ticket, gen, error, pad[29];
+};
+constexpr int PERSIST_BLOCK = 256;
+constexpr unsigned PERSIST_SPIN_LIMIT = 4000000u;
+
+template <bool WEIGHTED, bool BALL>
+__global__ __launch_bounds__(PERSIST_BLOCK) void icp_persistent_kernel(
+    const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
+    StepArgs A, double *__restrict__ partials, double *__restrict__ pose64, float *__restrict__ pose32,
+    double *__restrict__ err_hist, IcpCtl *__restrict__ ctl, int nblk, int iters, int iters_cap, int want_err, int ball_r)
+{
+    constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
+    constexpr int NW = PERSIST_BLOCK / 64;
+    __shared__ double wsum[NW][NACC];
+    __shared__ double tslab[NW][8][64];
+    __shared__ float s_pose[12];
+    __shared__ int s_flag;
+
+    const int lb = xcd_remap(blockIdx.x, nblk);
+    const int b = __builtin_amdgcn_readfirstlane(blk_pair[lb]);
+    const int first = __builtin_amdgcn_readfirstlane(blk_first[lb]);
+    const PairDesc &P = pairs[b];
+    const int src_n = P.n, nb_pair = P.pblk_cnt, slot0 = P.pblk_off;
+    const long long src_off = P.src_off, tgt_off = P.tgt_off;
+    IcpCtl *c = ctl + b;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    for (int it = 0; it < iters; ++it) {
+        if (threadIdx.x < 12) s_pose[threadIdx.x] = ld_agent(pose32 + (size_t)b * 12 + threadIdx.x);
+        __syncthreads();
+        step_body<1, WEIGHTED, BALL, PERSIST_BLOCK>(A, P, s_pose, first, src_n, src_off, tgt_off, ball_r << 8,
+                                                    (it == iters - 1 ? 1 : 0) | (want_err ? 0 : 2), wsum, tslab);
+        __syncthreads();
+        if (threadIdx.x < NACC) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += wsum[w][threadIdx.x];
+            st_agent(partials + (size_t)lb * NACC + threadIdx.x, v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the workgroup signals
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(&c->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_flag = t == (unsigned)(it + 1) * (unsigned)nb_pair - 1u ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_flag && wave == 0) {  // this workgroup delivered the pair's last partial sums: it solves
+            double a[NACC];
+#pragma unroll
+            for (int k = 0; k < NACC; ++k) a[k] = 0.0;
+            for (int j = lane; j < nb_pair; j += 64) {
+                const double *pp = partials + (size_t)(slot0 + j) * NACC;
+#pragma unroll
+                for (int k = 0; k < NACC; ++k) a[k] += ld_agent(pp + k);
+            }
+#pragma unroll
+            for (int k = 0; k < NACC; ++k) a[k] = wave_sum(a[k]);
+            if (lane == 0) {
+                solve_pose<WEIGHTED, true>(a, pose64 + (size_t)b * 16, pose32 + (size_t)b * 12,
+                                           want_err ? err_hist + (size_t)b * iters_cap + it : nullptr);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                st_agent(&c->gen, (unsigned)(it + 1));
+            }
+        }
+        if (it + 1 == iters) break;  // nobody reads the last pose inside the launch
+        if (threadIdx.x == 0) {  // wait for the pair's new pose
+            unsigned spins = 0;
+            int bad = 0;
+            while (ld_agent(&c->gen) < (unsigned)(it + 1)) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > PERSIST_SPIN_LIMIT || ld_agent(&c->error) != 0u) {
+                    st_agent(&c->error, 1u);
+                    bad = 1;
+                    break;
+                }
+            }
+            s_flag = bad;
+        }
+        __syncthreads();
+        if (s_flag) return;  // (uniform) a wait ran out: give up, the host reports it
+        __syncthreads();     // s_flag is written again next iteration
     }
 }
 
@@ -1021,6 +1186,8 @@ struct gpscal_scan_batch {
     bool weighted = false;
     int qpt = 1, nblk = 0, diag = 0;
     int step_block = 128;  // threads per workgroup of icp_step_kernel (128 or 256, by batch size)
+    bool persistent = false;  // small batch: all iterations of a run in ONE launch (icp_persistent_kernel)
+    DevBuf<IcpCtl> ctl;
     int uni_n = 0, uni_m = 0, uni_bpp = 0;  // equal-sized scans stored back to back: workgroup slices by arithmetic
     int ball_r = 0;  // block radius of the ball search (0 = fine -> coarse 3x3x3 search)
     DevBuf<PairDesc> pairs;  // target descs + source fields
@@ -1205,6 +1372,15 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
         P.pblk_cnt = (int)bp.size() - P.pblk_off;
     }
     B->nblk = (int)bp.size();
+    // GPSCAL_ICP_PERSISTENT=1: a batch whose step grid is resident all at once runs the iterations of a run in ONE
+    // launch (icp_persistent_kernel) instead of the captured graph.  Off by default: measured on one 65 536-point
+    // pair it is no faster (33.3 k against 35.1 k iterations/s) -- the run is the sum of the step's own dependent
+    // search chains (1.03 ms of the 1.5 ms), and the in-kernel hand-off + solve (9.4 us per iteration) costs what
+    // the two launches cost.
+    B->persistent = false;
+    if (const char *e = getenv("GPSCAL_ICP_PERSISTENT"))
+        B->persistent = atoi(e) != 0 && B->qpt == 1 && B->step_block == PERSIST_BLOCK && B->nblk >= 1 &&
+                        B->nblk <= 2 * ctx->prop.multiProcessorCount;
     // equal-sized scans stored back to back (the usual batch): the step kernel finds a workgroup's slice by arithmetic
     {
         bool uni = np > 0 && B->hpairs[0].n > 0;
@@ -1266,6 +1442,7 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
     hipLaunchKernelGGL(fill_warm_kernel, dim3(div_up(std::max<long long>(B->total_n, 1), BLOCK)), dim3(BLOCK), 0,
                        ctx->stream, B->warm_q.p, B->warm_r2.p, B->total_n);
     GPSCAL_HIP(ctx, B->partials.alloc_async((size_t)std::max(B->nblk, 1) * NACC_WEIGHTED, ctx->stream));
+    if (B->persistent) GPSCAL_HIP(ctx, B->ctl.alloc_async((size_t)np, ctx->stream));
     GPSCAL_HIP(ctx, B->pose64.alloc_async((size_t)np * 16, ctx->stream));
     GPSCAL_HIP(ctx, B->pose32.alloc_async((size_t)np * 12, ctx->stream));
     GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1427,6 +1604,25 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
         GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int it = 0; it < iters; ++it) GPSCAL_HIP(ctx, hipEventElapsedTime(&step_ms[it], ev[2 * it], ev[2 * it + 1]));
         for (auto &e : ev) (void)hipEventDestroy(e);
+    } else if (iters > 0 && B->persistent) {
+        GridSet &G = *B->tgt;
+        GPSCAL_HIP(ctx, hipMemsetAsync(B->ctl.p, 0, sizeof(IcpCtl) * np, ctx->stream));
+        if (want_err)  // (a pair without source points has no workgroup: its history reads zero, as the solve kernel leaves it)
+            GPSCAL_HIP(ctx, hipMemsetAsync(B->err_hist.p, 0, sizeof(double) * (size_t)np * B->err_cap, ctx->stream));
+        const StepArgs A = {B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p, G.cell_start,
+                            B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p};
+#define PERSIST(W, BALL)                                                                                            \
+    hipLaunchKernelGGL((icp_persistent_kernel<W, BALL>), dim3(B->nblk), dim3(PERSIST_BLOCK), 0, ctx->stream,         \
+                       B->pairs.p, B->blk_pair.p, B->blk_first.p, A, B->partials.p, B->pose64.p, B->pose32.p,        \
+                       B->err_hist.p, B->ctl.p, B->nblk, iters, B->err_cap, want_err ? 1 : 0, B->ball_r)
+        const bool ball = B->ball_r > 0;
+        if (B->weighted) {
+            if (ball) PERSIST(true, true); else PERSIST(true, false);
+        } else {
+            if (ball) PERSIST(false, true); else PERSIST(false, false);
+        }
+#undef PERSIST
+        GPSCAL_HIP(ctx, hipGetLastError());
     } else if (iters > 0) {
         const int gkey = 2 * iters + (want_err ? 1 : 0);  // a graph per (iteration count, error history wanted)
         int slot = -1;
@@ -1487,6 +1683,12 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
         sync = sync || kind == hipMemcpyDeviceToHost;
     }
     if (sync) GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (sync && B->persistent && iters > 0 && !step_ms) {  // a bounded wait of the persistent kernel ran out?
+        std::vector<IcpCtl> hc((size_t)np);
+        GPSCAL_HIP(ctx, hipMemcpy(hc.data(), B->ctl.p, sizeof(IcpCtl) * np, hipMemcpyDeviceToHost));
+        for (const IcpCtl &c : hc)
+            if (c.error) return fail(ctx, GPSCAL_EHIP, "icp_persistent_kernel: a workgroup waited too long for its pair's pose");
+    }
     return GPSCAL_OK;
 }
 

@@ -567,16 +567,17 @@ def _ragged_batch(npairs, n):
 def test_icp_graph_chains_and_slices_agree_with_each_other_and_the_oracle(ctx, monkeypatch, ragged):
     """What the headline benchmark runs -- the captured graph with several step -> solve chains, chain-local block
     and partial-sum offsets, workgroup slices by arithmetic -- against the whole-batch launches of the profiling mode,
-    against one chain, against the table-driven slices and against both workgroup sizes of the step kernel, bit for
-    bit; and against the kd-tree oracle.  12 pairs: two chains by default, four forced; the ragged batch has a
+    against one chain, against the table-driven slices, against the one-launch persistent kernel (GPSCAL_ICP_PERSISTENT=1:
+    all iterations of a small batch in one launch), and against both workgroup sizes of the step kernel, bit for bit; and against the kd-tree oracle.  12 pairs: two chains by default, four forced; the ragged batch has a
     five-point and a one-point source and a sparse target, so chains split unevenly and slices come from the table."""
     npairs, n, iters = 12, 4096, 12
     if ragged:
         tg, to, sr, so = _ragged_batch(npairs, n)
     else:
         tg, to, sr, so, _ = synth.scan_batch(npairs, n)
-    variants = {"default": {}, "chains1": {"GPSCAL_ICP_CHAINS": "1"}, "chains4": {"GPSCAL_ICP_CHAINS": "4"},
-                "table": {"GPSCAL_ICP_UNIFORM": "0"}, "wg128": {"GPSCAL_STEP_BLOCK": "128", "GPSCAL_ICP_CHAINS": "4"}}
+    variants = {"default": {}, "persistent": {"GPSCAL_ICP_PERSISTENT": "1"}, "chains1": {"GPSCAL_ICP_CHAINS": "1"},
+                "chains4": {"GPSCAL_ICP_CHAINS": "4"}, "table": {"GPSCAL_ICP_UNIFORM": "0"},
+                "wg128": {"GPSCAL_STEP_BLOCK": "128", "GPSCAL_ICP_CHAINS": "4"}}
     runs = {}
     for name, env in variants.items():
         for k, v in env.items():
@@ -594,7 +595,7 @@ def test_icp_graph_chains_and_slices_agree_with_each_other_and_the_oracle(ctx, m
             sb.set_pose(None)
             T_prev, _, _ = sb.icp(iters - 1)
         sb.close()
-    for name in ("chains1", "chains4", "table"):
+    for name in ("persistent", "chains1", "chains4", "table"):
         assert all(np.array_equal(a, b) for a, b in zip(runs["default"], runs[name])), name
     # another workgroup size adds the float64 sums in another order: last bits of the pose, never a correspondence
     assert np.abs(runs["wg128"][0] - runs["default"][0]).max() < 1e-9

@@ -6,7 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from gpscalibration_amd import Context, synth
-npairs, n, iters = 64, 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 50
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 tg, to, sr, so, _ = synth.scan_batch(npairs, n)
 ctx = Context(0)
 sb = ctx.scan_batch(torch.from_numpy(tg).cuda(), to, torch.from_numpy(sr).cuda(), so)
