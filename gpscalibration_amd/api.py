@@ -25,7 +25,8 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
-_DEVICE_ARG = [False]  # a CUDA tensor went into the argument list being built (see _Ordered)
+class _DevPtr(C.c_void_p):
+    """The address of a CUDA tensor: _Ordered.call orders the library's stream against torch's for calls that get one."""
 
 
 def _ptr(x):
@@ -33,9 +34,7 @@ def _ptr(x):
         return None
     if _is_torch(x):
         assert x.is_contiguous()
-        if x.is_cuda:
-            _DEVICE_ARG[0] = True
-        return C.c_void_p(x.data_ptr())
+        return _DevPtr(x.data_ptr()) if x.is_cuda else C.c_void_p(x.data_ptr())
     assert x.flags["C_CONTIGUOUS"]
     return C.c_void_p(x.ctypes.data)
 
@@ -65,9 +64,10 @@ class _Ordered:
         fn = getattr(self._L, name)
 
         def call(*args):
-            if not _DEVICE_ARG[0]:
+            # (the marker travels with the argument list: no state shared between threads or left behind by a
+            # failed call)
+            if not any(isinstance(a, _DevPtr) for a in args):
                 return fn(*args)
-            _DEVICE_ARG[0] = False
             import torch
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             self._L.gpscal_wait_for_stream(self._ctx._h, stream)
@@ -90,9 +90,22 @@ class Context:
         self._h = h
         self._L = _Ordered(L, self)
         self.device_id = device_id
+        self._children = []  # weak references to the scan batches and k-NN indexes built on this context
+
+    def _adopt(self, child):
+        import weakref
+        self._children = [r for r in self._children if r() is not None]
+        self._children.append(weakref.ref(child))
+        return child
 
     def close(self):
         if getattr(self, "_h", None):
+            # whatever still lives on this context goes first: its device blocks belong to the context's stream cache
+            for r in getattr(self, "_children", []):
+                c = r()
+                if c is not None:
+                    c.close()
+            self._children = []
             self._L.gpscal_destroy(self._h)
             self._h = None
 
@@ -408,10 +421,10 @@ class Context:
 
     # ------------------------------------------------------------ factories
     def knn_index(self, xyz, stride_bytes=12, cell_size=0.0):
-        return KnnIndex(self, xyz, stride_bytes, cell_size)
+        return self._adopt(KnnIndex(self, xyz, stride_bytes, cell_size))
 
     def scan_batch(self, tgt_xyz, tgt_off, src_xyz, src_off, w=None, cell_size=0.0):
-        return ScanBatch(self, tgt_xyz, tgt_off, src_xyz, src_off, w, cell_size)
+        return self._adopt(ScanBatch(self, tgt_xyz, tgt_off, src_xyz, src_off, w, cell_size))
 
 
 class KnnIndex:

@@ -50,6 +50,7 @@ extern "C" int gpscal_create(gpscal_ctx **out, int device_id, unsigned flags)
         delete ctx;
         return GPSCAL_ENODEV;
     }
+    cache_revive(ctx->stream);
     *out = ctx;
     return GPSCAL_OK;
 }
@@ -66,9 +67,15 @@ extern "C" int gpscal_destroy(gpscal_ctx *ctx)
         if (ctx->side_stream[k]) (void)hipStreamDestroy(ctx->side_stream[k]);
         if (ctx->side_event[k]) (void)hipEventDestroy(ctx->side_event[k]);
     }
+    if (ctx->worker_stream) {
+        (void)hipStreamSynchronize(ctx->worker_stream);
+        cache_retire(ctx->worker_stream);
+        (void)hipStreamDestroy(ctx->worker_stream);
+    }
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
-        cache_trim(ctx->stream);  // the stream's cached temporaries go back to the driver
+        cache_retire(ctx->stream);  // the stream's cached temporaries go back to the driver; a batch or index that
+                                    // outlives the context frees its blocks plainly (cache_free)
         (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;

@@ -13,6 +13,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/gpscal.h"
@@ -25,6 +26,9 @@ struct gpscal_ctx {
     static constexpr int MAX_SIDE = 8;
     hipStream_t side_stream[MAX_SIDE] = {};
     hipEvent_t side_event[MAX_SIDE] = {};
+    // worker stream of the LOAM chain's second node thread (created on first use, kept: its block cache then serves
+    // every later run; destroyed and trimmed by gpscal_destroy)
+    hipStream_t worker_stream = nullptr;
     hipDeviceProp_t prop{};
     std::string last_error;
     void *comm = nullptr;  // ncclComm_t, owned by comm.hip
@@ -121,11 +125,22 @@ inline std::mutex &cache_registry_mutex()
     static std::mutex *m = new std::mutex;  // leaked on purpose: no static-destruction order to worry about
     return *m;
 }
-inline BlockCache &cache_of(hipStream_t stream)
+inline std::unordered_map<hipStream_t, BlockCache *> &cache_registry()
 {
     static auto *reg = new std::unordered_map<hipStream_t, BlockCache *>;
+    return *reg;
+}
+// streams whose cache has been retired (the stream was destroyed): a block that comes back for one of them
+// -- a scan batch destroyed after its context -- goes straight to hipFree
+inline std::unordered_set<hipStream_t> &cache_retired()
+{
+    static auto *dead = new std::unordered_set<hipStream_t>;
+    return *dead;
+}
+inline BlockCache &cache_of(hipStream_t stream)
+{
     std::lock_guard<std::mutex> lk(cache_registry_mutex());
-    BlockCache *&c = (*reg)[stream];
+    BlockCache *&c = cache_registry()[stream];
     if (!c) c = new BlockCache;
     return *c;
 }
@@ -139,6 +154,38 @@ inline void cache_trim(hipStream_t stream, size_t keep_bytes = 0)
         (void)hipFree(it->second);
         C.cached_bytes -= it->first;
         C.free_blocks.erase(it);
+    }
+}
+// A new stream starts with a live cache (the runtime may hand out the handle of a destroyed stream again).
+inline void cache_revive(hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(cache_registry_mutex());
+    cache_retired().erase(stream);
+}
+// The stream is about to be destroyed (the caller has synchronised it): its cached blocks go back to the driver, its
+// registry entry goes, and blocks still handed out are freed plainly when they come back.
+inline void cache_retire(hipStream_t stream)
+{
+    cache_trim(stream);
+    std::lock_guard<std::mutex> lk(cache_registry_mutex());
+    auto it = cache_registry().find(stream);
+    if (it != cache_registry().end()) {
+        delete it->second;
+        cache_registry().erase(it);
+    }
+    cache_retired().insert(stream);
+}
+// Out of memory: what idles in ANY stream's cache is given back (up to an eighth of the device per stream may sit there).
+inline void cache_trim_all()
+{
+    std::vector<hipStream_t> streams;
+    {
+        std::lock_guard<std::mutex> lk(cache_registry_mutex());
+        for (auto &kv : cache_registry()) streams.push_back(kv.first);
+    }
+    for (hipStream_t st : streams) {
+        (void)hipStreamSynchronize(st);  // work that uses a cached block may still be queued
+        cache_trim(st);
     }
 }
 inline hipError_t cache_alloc(void **out, size_t bytes, hipStream_t stream)
@@ -157,10 +204,9 @@ inline hipError_t cache_alloc(void **out, size_t bytes, hipStream_t stream)
         }
     }
     hipError_t e = hipMalloc(out, need);
-    if (e != hipSuccess) {  // make room: drop what is cached (work using it may still be queued)
+    if (e != hipSuccess) {  // make room: drop what is cached, here and in every other stream's cache
         (void)hipGetLastError();
-        (void)hipStreamSynchronize(stream);
-        cache_trim(stream);
+        cache_trim_all();
         e = hipMalloc(out, need);
         if (e != hipSuccess) return e;
     }
@@ -186,6 +232,13 @@ inline size_t cache_cap()
 }
 inline void cache_free(void *p, hipStream_t stream)
 {
+    {
+        std::lock_guard<std::mutex> lk(cache_registry_mutex());
+        if (cache_retired().count(stream)) {  // the stream is gone: nothing to order the reuse against
+            (void)hipFree(p);
+            return;
+        }
+    }
     const size_t CACHE_CAP = cache_cap();
     BlockCache &C = cache_of(stream);
     bool trim = false;

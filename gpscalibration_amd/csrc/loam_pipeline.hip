@@ -32,6 +32,19 @@
 
 namespace gpscal {
 
+// The context's worker stream (the second node thread of the LOAM chain enqueues on it): created once, so that its
+// block cache serves every later run; gpscal_destroy retires it.
+static hipError_t worker_stream_of(gpscal_ctx *ctx, hipStream_t *out)
+{
+    if (!ctx->worker_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->worker_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        cache_revive(ctx->worker_stream);
+    }
+    *out = ctx->worker_stream;
+    return hipSuccess;
+}
+
 constexpr int LW = 21, LH = 11, LDp = 21, LNUM = LW * LH * LDp;  // LM:72-75
 constexpr int MAXVALID = 125;
 
@@ -1453,7 +1466,7 @@ extern "C" int gpscal_loam_run_batched(gpscal_ctx *ctx, int nseg, const float *x
             // scanRegistration's topics only), so the results are those of the lock-step order.
             gpscal_ctx octx = *ctx;  // same device, another stream; errors are copied back
             hipStream_t os = nullptr;
-            GPSCAL_HIP(ctx, hipStreamCreateWithFlags(&os, hipStreamNonBlocking));
+            GPSCAL_HIP(ctx, worker_stream_of(ctx, &os));
             octx.stream = os;
             std::mutex mu;
             std::condition_variable cv;
@@ -1508,9 +1521,7 @@ extern "C" int gpscal_loam_run_batched(gpscal_ctx *ctx, int nseg, const float *x
                 if (rc_m) break;
             }
             odo.join();
-            (void)hipStreamSynchronize(os);
-            cache_trim(os);
-            (void)hipStreamDestroy(os);
+            (void)hipStreamSynchronize(os);  // (the stream and its cached blocks stay with the context)
             if (rc_o) {
                 ctx->last_error = octx.last_error;
                 return rc_o;
@@ -1675,17 +1686,13 @@ extern "C" int gpscal_input_data_run(gpscal_ctx *ctx, int nbag, const float *xyz
                 cv.notify_all();
                 th.join();
             }
-            if (os) {
-                (void)hipStreamSynchronize(os);
-                cache_trim(os);
-                (void)hipStreamDestroy(os);
-            }
+            if (os) (void)hipStreamSynchronize(os);  // (the stream and its cached blocks stay with the context)
         }
     } mapper;
     if (loam_pipelined()) {
         mapper.P = &P;
         mapper.octx = *ctx;
-        GPSCAL_HIP(ctx, hipStreamCreateWithFlags(&mapper.os, hipStreamNonBlocking));
+        GPSCAL_HIP(ctx, worker_stream_of(ctx, &mapper.os));
         mapper.octx.stream = mapper.os;
         mapper.th = std::thread([&mapper] { mapper.run(); });
         mapper.on = true;

@@ -288,3 +288,26 @@ def test_scan_batch_and_knn_under_the_system_hip_runtime():
         "s2 = ctx.scan_batch(tg, to, sr, so); assert same(ref, run(s2, True)); print('ok')\n" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and b"ok" in r.stdout, r.stdout.decode()[-3000:]
+
+
+def test_context_close_takes_its_batches_and_indexes_first():
+    """A scan batch's state and a k-NN index are blocks of their context's stream cache (csrc/common.hpp): the
+    binding closes whatever still lives on a context before the context itself, so that the order in which Python
+    drops the objects does not matter; closing them again afterwards is a no-op."""
+    from gpscalibration_amd import Context, synth
+    c = Context(0)
+    tgt, src, _ = synth.scan_pair(4096, 2)
+    off = np.array([0, len(tgt)], dtype=np.int64)
+    sb = c.scan_batch(tgt, off, src, off)
+    ix = c.knn_index(tgt)
+    T, _, _ = sb.icp(3)
+    assert np.isfinite(T).all()
+    c.close()
+    assert sb._h is None and ix._h is None
+    sb.close()
+    ix.close()
+    c2 = Context(0)  # a new context (possibly the old stream handle again) starts with a live cache
+    sb2 = c2.scan_batch(tgt, off, src, off)
+    T2, _, _ = sb2.icp(3)
+    assert np.array_equal(T, T2)
+    c2.close()
