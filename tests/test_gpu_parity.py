@@ -611,6 +611,39 @@ def test_icp_graph_chains_and_slices_agree_with_each_other_and_the_oracle(ctx, m
         assert np.array_equal(idx[so[p]:so[p + 1]], ridx[:, 0]) and np.array_equal(sqd[so[p]:so[p + 1]], rsqd[:, 0]), p
 
 
+def test_icp_learnt_schedule_of_large_batches(ctx, monkeypatch):
+    """A batch of a million source points or more learns from its first run (from a fresh pose) at which iteration its
+    queries stop searching, and runs the later iterations of later runs on icp_step_multi_kernel (two queries per
+    lane).  The two kernels add their float64 sums in different orders: the first run and the later ones agree to the
+    last bits but one (never in a correspondence), later runs among themselves and with the profiling mode bit for
+    bit, and a batch with the switch disabled (GPSCAL_ICP_MULTI_BELOW=0) gives the first run's bits every time."""
+    npairs, n, iters = 16, 65536, 30
+    tg, to, sr, so, _ = synth.scan_batch(npairs, n)
+    sb = ctx.scan_batch(tg, to, sr, so)
+    runs = []
+    for k in range(4):
+        sb.set_pose(None)  # (a host pose: the call waits for the previous run, so its history has arrived)
+        T, err, _ = sb.icp(iters, profile=(k == 3))
+        idx, sqd = sb.correspondences()
+        runs.append((T.copy(), err.copy(), idx, sqd))
+    sb.close()
+    assert not np.array_equal(runs[0][0], runs[1][0])  # the switch happened ...
+    assert np.abs(runs[0][0] - runs[1][0]).max() < 1e-12 and np.abs(runs[0][1] - runs[1][1]).max() < 1e-12  # ... and is harmless
+    assert np.array_equal(runs[0][2], runs[1][2]) and np.array_equal(runs[0][3], runs[1][3])
+    for r in runs[2:]:
+        assert all(np.array_equal(a, b) for a, b in zip(runs[1], r))
+    monkeypatch.setenv("GPSCAL_ICP_MULTI_BELOW", "0")
+    pinned = ctx.scan_batch(tg, to, sr, so)
+    monkeypatch.delenv("GPSCAL_ICP_MULTI_BELOW")
+    for k in range(2):
+        pinned.set_pose(None)
+        T, err, _ = pinned.icp(iters)
+        assert np.array_equal(T, runs[0][0]) and np.array_equal(err, runs[0][1])
+    pinned.close()
+    T_ref, hist = O.KdTree(tg[to[5]:to[6]]).icp_run(sr[so[5]:so[6]], iters)
+    assert np.abs(runs[1][0][5] - T_ref).max() < 1e-5 and np.abs(runs[1][1][5] - hist).max() < 1e-5
+
+
 @pytest.mark.parametrize("npairs,n,iters", [(8, 262144, 20), (4, 1048576, 10)])
 def test_icp_batches_at_the_benchmark_shapes_match_oracle(ctx, npairs, n, iters):
     """Many-pair batches at the sizes of BASELINE configs[3] / [4] through ONE scan batch (the index of such a batch
