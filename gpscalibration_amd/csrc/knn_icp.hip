@@ -689,8 +689,14 @@ __device__ __forceinline__ void wave_reduce_acc(const double *acc, double *__res
 // (nearly) stopped searching (gpscal_scan_batch_icp).  A workgroup covers QPT slices of STEP_BLOCK points, i.e. QPT
 // partial-sum slots of the icp_step_kernel layout: it writes its sums to the first and zeros to the others, so the
 // solve kernel needs no second layout.
+#ifndef GPSCAL_MULTI_MINW
+#define GPSCAL_MULTI_MINW 6  // waves per SIMD the register allocation aims at (80 VGPRs; measured with 2 queries per lane)
+#endif
+#ifndef GPSCAL_MULTI_QPT
+#define GPSCAL_MULTI_QPT 2
+#endif
 template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK>
-__global__ __launch_bounds__(STEP_BLOCK, 6) void icp_step_multi_kernel(
+__global__ __launch_bounds__(STEP_BLOCK, GPSCAL_MULTI_MINW) void icp_step_multi_kernel(
     const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first, StepArgs A,
     const float *__restrict__ pose32, double *__restrict__ partials, int nblk, int diag, int write_nn, int uni_n, int uni_m,
     int uni_bpp, int uni_mbpp, int uni_pair0, unsigned *__restrict__ srch_cnt)
@@ -1467,7 +1473,7 @@ struct gpscal_scan_batch {
     // previous run of the batch from a fresh pose: the solve kernel records how many queries of every pair searched in
     // every iteration, the history comes back asynchronously, and the switch is put behind the last iteration in which
     // multi_below of the queries (or more) searched.  Until a history is known nothing is switched.
-    static constexpr int MULTI_QPT = 2;
+    static constexpr int MULTI_QPT = GPSCAL_MULTI_QPT;
     float multi_below = 0.03f;
     int sched_k[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};  // per chain
     long long iters_done = 0;  // iterations since set_pose
