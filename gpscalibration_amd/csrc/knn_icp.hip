@@ -1474,7 +1474,7 @@ struct gpscal_scan_batch {
     // every iteration, the history comes back asynchronously, and the switch is put behind the last iteration in which
     // multi_below of the queries (or more) searched.  Until a history is known nothing is switched.
     static constexpr int MULTI_QPT = GPSCAL_MULTI_QPT;
-    float multi_below = 0.03f;
+    float multi_below = 0.01f;
     int sched_k[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};  // per chain
     long long iters_done = 0;  // iterations since set_pose
     DevBuf<int> mblk_pair, mblk_first;
