@@ -1962,6 +1962,11 @@ static void learn_schedule(gpscal_scan_batch *B)
         // (still searching at the end of what is known: nothing is known about later iterations)
         if (k < B->hist_iters) B->sched_k[c] = k;
     }
+    if (getenv("GPSCAL_SCHED_DEBUG")) {
+        fprintf(stderr, "icp schedule learnt from %d iterations:", B->hist_iters);
+        for (int c = 0; c < B->nchains; ++c) fprintf(stderr, " chain %d -> %d", c, B->sched_k[c]);
+        fprintf(stderr, "\n");
+    }
 }
 
 extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_out, double *mean_err,
