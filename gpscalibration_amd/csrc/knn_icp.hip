@@ -394,6 +394,103 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
 // `first`) through transform, certificates and search; leaves every wave's sums in wsum[wave][0 .. NACC) (the caller
 // synchronises the workgroup and adds them).  T: the pair's float32 pose (12 values).  Shared by icp_step_kernel
 // (one launch per iteration) and icp_persistent_kernel (all iterations of small batches in one launch).
+// ---- the sums of one iteration.  Both step kernels are bound by the issue rate of vector instructions (SQ counters,
+// round 3: 80 % of the issue slots in the searching iterations, 91 % in the converged ones), so the sums are written
+// for instruction count: a lane without a correspondence contributes zeros through zeroed INPUTS (straight-line
+// code, no masked block), products enter by one fma, the number of correspondences is counted by ballot on the
+// scalar unit instead of a 17th float64 sum, and sqrt((double)d2) is a float32 rsq with one float64 Newton step.
+template <bool WEIGHTED>
+struct SumLayout {
+    static constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
+    static constexpr int NT = NACC - 1;                  // float64 terms a lane carries
+    static constexpr int COUNT = WEIGHTED ? 24 : 0;      // the sum that is the number of correspondences
+    static constexpr int FIRST = WEIGHTED ? 0 : 1;       // term j is sum FIRST + j
+};
+
+// sqrt((double)d2) for a float32 d2 >= 0 to 2e-14 relative (v_rsq_f32 is good to 1 ulp = delta, the Newton step
+// leaves 1.5 delta^2); 0 for zero and denormal d2.  7 instructions against ~22 for the correctly rounded sqrt.
+__device__ __forceinline__ double sqrt_of_f32(float d2)
+{
+    const float y = d2 >= 1.17549435e-38f ? __builtin_amdgcn_rsqf(d2) : 0.f;
+    const double D = d2, Y = y;
+    const double s = D * Y;
+    const double e = __fma_rn(-s, s, D);
+    return __fma_rn(e * Y, 0.5, s);
+}
+
+// One correspondence into the lane's terms.  INIT: the terms are set, not added to (the first query of a lane).
+// A lane without a correspondence passes found = false: its inputs become zeros, so do its terms.
+template <bool WEIGHTED, bool INIT>
+__device__ __forceinline__ void pair_terms(double *t, bool found, float px, float py, float pz, const float4 &nq,
+                                           float bd, double w, bool want_dist)
+{
+    const double dpx = found ? px : 0.f, dpy = found ? py : 0.f, dpz = found ? pz : 0.f;
+    const double qx = found ? nq.x : 0.f, qy = found ? nq.y : 0.f, qz = found ? nq.z : 0.f;
+    const double dist = want_dist ? sqrt_of_f32(found ? bd : 0.f) : 0.0;
+#define GPSCAL_TERM(j, v) t[j] = INIT ? (v) : t[j] + (v)
+#define GPSCAL_PROD(j, a, b) t[j] = INIT ? (a) * (b) : __fma_rn(a, b, t[j])
+    if (WEIGHTED) {
+        if (!found) w = 0.0;
+        const double w2 = w * w;
+        GPSCAL_TERM(0, w);
+        GPSCAL_PROD(1, w, dpx); GPSCAL_PROD(2, w, dpy); GPSCAL_PROD(3, w, dpz);
+        GPSCAL_PROD(4, w, qx);  GPSCAL_PROD(5, w, qy);  GPSCAL_PROD(6, w, qz);
+        const double ax = w2 * dpx, ay = w2 * dpy, az = w2 * dpz;
+        GPSCAL_PROD(7, ax, qx);  GPSCAL_PROD(8, ax, qy);  GPSCAL_PROD(9, ax, qz);
+        GPSCAL_PROD(10, ay, qx); GPSCAL_PROD(11, ay, qy); GPSCAL_PROD(12, ay, qz);
+        GPSCAL_PROD(13, az, qx); GPSCAL_PROD(14, az, qy); GPSCAL_PROD(15, az, qz);
+        GPSCAL_TERM(16, dist);
+        GPSCAL_TERM(17, w2);
+        GPSCAL_TERM(18, ax); GPSCAL_TERM(19, ay); GPSCAL_TERM(20, az);
+        GPSCAL_PROD(21, w2, qx); GPSCAL_PROD(22, w2, qy); GPSCAL_PROD(23, w2, qz);
+    } else {
+        GPSCAL_TERM(0, dpx); GPSCAL_TERM(1, dpy); GPSCAL_TERM(2, dpz);
+        GPSCAL_TERM(3, qx);  GPSCAL_TERM(4, qy);  GPSCAL_TERM(5, qz);
+        GPSCAL_PROD(6, dpx, qx);  GPSCAL_PROD(7, dpx, qy);  GPSCAL_PROD(8, dpx, qz);
+        GPSCAL_PROD(9, dpy, qx);  GPSCAL_PROD(10, dpy, qy); GPSCAL_PROD(11, dpy, qz);
+        GPSCAL_PROD(12, dpz, qx); GPSCAL_PROD(13, dpz, qy); GPSCAL_PROD(14, dpz, qz);
+        GPSCAL_TERM(15, dist);
+    }
+#undef GPSCAL_TERM
+#undef GPSCAL_PROD
+}
+
+// v + (v of the lane `shift` below in the row, 0 beyond the row's start): bound_ctrl supplies the zero, so no
+// register has to be cleared in front of the move.
+template <int CTRL>
+__device__ __forceinline__ double dpp_shr_add_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return v + __hiloint2double(hi, lo);
+}
+
+// Sum of every term over the 64 lanes, in fixed order: 8 terms at a time are transposed through the wave's slab
+// (lane (k, seg) adds 8 consecutive lanes' copies of term k, three DPP steps fold the 8 segments); lane 8k+7 ends up
+// with term g0+k and hands it to `sink(term, value)`.  ~20 vector instructions per 8 terms against ~160 for 8 full
+// DPP wave reductions.
+template <int NT, class Sink>
+__device__ __forceinline__ void wave_reduce_terms(const double *t, double *__restrict__ slab, Sink sink)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = lane >> 3, seg = lane & 7;
+    const double2 *row = reinterpret_cast<const double2 *>(slab + k * 64 + seg * 8);
+#pragma unroll
+    for (int g0 = 0; g0 < NT; g0 += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (g0 + j < NT) slab[j * 64 + lane] = t[g0 + j];
+        __builtin_amdgcn_wave_barrier();
+        const double2 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+        double v = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
+        v = dpp_shr_add_f64<0x111>(v);  // row_shr:1
+        v = dpp_shr_add_f64<0x112>(v);  // row_shr:2
+        v = dpp_shr_add_f64<0x114>(v);  // row_shr:4 -> lane 8k+7 holds term k
+        if (seg == 7 && g0 + k < NT) sink(g0 + k, v);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 struct StepArgs {
     const float4 *__restrict__ src4;
     const double *__restrict__ wsrc;
@@ -412,7 +509,6 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
                                           double (&wsum)[STEP_BLOCK / 64][WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN],
                                           double (&tslab)[STEP_BLOCK / 64][8][64])
 {
-    constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
     const float4 *__restrict__ src4 = A.src4;
     const double *__restrict__ wsrc = A.wsrc;
     const float4 *__restrict__ sorted = A.sorted;
@@ -428,9 +524,13 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
     const float r20 = T[8], r21 = T[9], r22 = T[10], tz = T[11];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    double acc[NACC];
+    using SL = SumLayout<WEIGHTED>;
+    double t[SL::NT];
+    if (QPT > 1) {
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+        for (int k = 0; k < SL::NT; ++k) t[k] = 0.0;
+    }
+    unsigned n_found = 0;  // correspondences of this wave
     unsigned n_need = 0;  // queries of this wave that took the grid search (what the schedule of a batch is learnt from)
 
 #pragma unroll 1
@@ -480,8 +580,8 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
         STAT_WAVE(2, __ballot(need) != 0ull ? 1 : 0);
         STAT_WAVE(17, __popcll(__ballot(ok && !need && B.pos != BestQ::WARM)));  // settled by tier 2 with a new neighbour
 #endif
-        knn_query<BestQ, BALL>(P, sorted, cell_start, need, px, py, pz, B, diag >> 8);
-        if (!valid) continue;
+        if (__ballot(need) != 0ull)  // wave-uniform: a settled wave skips the search's set-up as well
+            knn_query<BestQ, BALL>(P, sorted, cell_start, need, px, py, pz, B, diag >> 8);
         ok = ok && B.index() != 0x7fffffff;
         if (ok && B.pos != BestQ::WARM) {
             // the neighbour changed: remember it and its radii for the next iteration
@@ -492,64 +592,17 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
             warm_r2[src_off + i] = (__float_as_uint(r2.x) & 0xffff0000u) | (__float_as_uint(r2.y) >> 16);
         }
         const float bd = B.dist2();
-        if (write_nn & 1) {  // the correspondences are an output of the run's last iteration only
+        if (valid && (write_nn & 1)) {  // the correspondences are an output of the run's last iteration only
             nn_idx[src_off + i] = ok ? B.index() : -1;
             nn_sqd[src_off + i] = ok ? bd : INFINITY;
         }
-        if (!ok) continue;
-        const double dpx = px, dpy = py, dpz = pz, qx = nq.x, qy = nq.y, qz = nq.z;
-        if (WEIGHTED) {
-            const double w = wsrc[src_off + i], w2 = w * w;
-            acc[0] += w;
-            acc[1] += w * dpx; acc[2] += w * dpy; acc[3] += w * dpz;
-            acc[4] += w * qx;  acc[5] += w * qy;  acc[6] += w * qz;
-            const double ax = w2 * dpx, ay = w2 * dpy, az = w2 * dpz;
-            acc[7] += ax * qx;  acc[8] += ax * qy;  acc[9] += ax * qz;
-            acc[10] += ay * qx; acc[11] += ay * qy; acc[12] += ay * qz;
-            acc[13] += az * qx; acc[14] += az * qy; acc[15] += az * qz;
-            if (!(write_nn & 2)) acc[16] += sqrt((double)bd);
-            acc[17] += w2;
-            acc[18] += ax; acc[19] += ay; acc[20] += az;
-            acc[21] += w2 * qx; acc[22] += w2 * qy; acc[23] += w2 * qz;
-            acc[24] += 1.0;
-        } else {
-            acc[0] += 1.0;
-            acc[1] += dpx; acc[2] += dpy; acc[3] += dpz;
-            acc[4] += qx;  acc[5] += qy;  acc[6] += qz;
-            acc[7] += dpx * qx;  acc[8] += dpx * qy;  acc[9] += dpx * qz;
-            acc[10] += dpy * qx; acc[11] += dpy * qy; acc[12] += dpy * qz;
-            acc[13] += dpz * qx; acc[14] += dpz * qy; acc[15] += dpz * qz;
-            // the mean correspondence distance is an output only when the caller asks for the error history
-            if (!(write_nn & 2)) acc[16] += sqrt((double)bd);
-        }
+        n_found += (unsigned)__popcll(__ballot(ok));
+        pair_terms<WEIGHTED, QPT == 1>(t, ok, px, py, pz, nq, bd, WEIGHTED ? (valid ? wsrc[src_off + i] : 0.0) : 1.0,
+                                       !(write_nn & 2));
     }
-    // Block reduction in fixed order.  Each wave transposes 8 accumulators at a time
-    // through its private LDS slab: lane (k, seg) sums 8 consecutive lanes' copies of
-    // value k (4 x ds_read_b128), three DPP steps fold the 8 segments.  ~80 VALU per
-    // wave against ~340 for 17 full DPP wave reductions (this kernel is VALU-bound).
-    if (diag & 2) {
-#pragma unroll
-        for (int k = 0; k < NACC; ++k)
-            if (lane == 0) wsum[wave][k] = acc[k];
-    } else {
-        double *slab = &tslab[wave][0][0];
-#pragma unroll
-        for (int g0 = 0; g0 < NACC; g0 += 8) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (g0 + k < NACC) slab[k * 64 + lane] = acc[g0 + k];
-            __builtin_amdgcn_wave_barrier();
-            const int k = lane >> 3, seg = lane & 7;
-            const double2 *row = reinterpret_cast<const double2 *>(slab + k * 64 + seg * 8);
-            const double2 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
-            double v = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
-            v = dpp_add_f64<0x111, 0xF>(v);  // row_shr:1
-            v = dpp_add_f64<0x112, 0xF>(v);  // row_shr:2
-            v = dpp_add_f64<0x114, 0xF>(v);  // row_shr:4 -> lane 8k+7 holds value k
-            if (seg == 7 && g0 + k < NACC) wsum[wave][g0 + k] = v;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
+    // Wave sums in fixed order (the caller adds the waves' rows)
+    wave_reduce_terms<SL::NT>(t, &tslab[wave][0][0], [&](int k, double v) { wsum[wave][SL::FIRST + k] = v; });
+    if (lane == 0) wsum[wave][SL::COUNT] = (double)n_found;
     return n_need;
 }
 
@@ -623,62 +676,6 @@ struct Pose32 {
     }
 };
 
-// One correspondence into the lane's sums (the order of operations of step_body).
-template <bool WEIGHTED>
-__device__ __forceinline__ void acc_pair(double *acc, float px, float py, float pz, const float4 &nq, float bd, double w,
-                                         bool want_dist)
-{
-    const double dpx = px, dpy = py, dpz = pz, qx = nq.x, qy = nq.y, qz = nq.z;
-    if (WEIGHTED) {
-        const double w2 = w * w;
-        acc[0] += w;
-        acc[1] += w * dpx; acc[2] += w * dpy; acc[3] += w * dpz;
-        acc[4] += w * qx;  acc[5] += w * qy;  acc[6] += w * qz;
-        const double ax = w2 * dpx, ay = w2 * dpy, az = w2 * dpz;
-        acc[7] += ax * qx;  acc[8] += ax * qy;  acc[9] += ax * qz;
-        acc[10] += ay * qx; acc[11] += ay * qy; acc[12] += ay * qz;
-        acc[13] += az * qx; acc[14] += az * qy; acc[15] += az * qz;
-        if (want_dist) acc[16] += sqrt((double)bd);
-        acc[17] += w2;
-        acc[18] += ax; acc[19] += ay; acc[20] += az;
-        acc[21] += w2 * qx; acc[22] += w2 * qy; acc[23] += w2 * qz;
-        acc[24] += 1.0;
-    } else {
-        acc[0] += 1.0;
-        acc[1] += dpx; acc[2] += dpy; acc[3] += dpz;
-        acc[4] += qx;  acc[5] += qy;  acc[6] += qz;
-        acc[7] += dpx * qx;  acc[8] += dpx * qy;  acc[9] += dpx * qz;
-        acc[10] += dpy * qx; acc[11] += dpy * qy; acc[12] += dpy * qz;
-        acc[13] += dpz * qx; acc[14] += dpz * qy; acc[15] += dpz * qz;
-        if (want_dist) acc[16] += sqrt((double)bd);
-    }
-}
-
-// Sum of every accumulator over the 64 lanes, in fixed order: 8 values at a time are transposed through the
-// wave's slab (lane (k, seg) adds 8 consecutive lanes' copies of value k, three DPP steps fold the 8 segments);
-// lane 8k+7 ends up with value g0+k and hands it to `sink(index, value)`.
-template <int NACC, class Sink>
-__device__ __forceinline__ void wave_reduce_acc(const double *acc, double *__restrict__ slab, Sink sink)
-{
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int g0 = 0; g0 < NACC; g0 += 8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (g0 + k < NACC) slab[k * 64 + lane] = acc[g0 + k];
-        __builtin_amdgcn_wave_barrier();
-        const int k = lane >> 3, seg = lane & 7;
-        const double2 *row = reinterpret_cast<const double2 *>(slab + k * 64 + seg * 8);
-        const double2 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
-        double v = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
-        v = dpp_add_f64<0x111, 0xF>(v);  // row_shr:1
-        v = dpp_add_f64<0x112, 0xF>(v);  // row_shr:2
-        v = dpp_add_f64<0x114, 0xF>(v);  // row_shr:4 -> lane 8k+7 holds value k
-        if (seg == 7 && g0 + k < NACC) sink(g0 + k, v);
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // The converged iterations' step kernel: QPT queries per lane in two phases.  Phase 1 has every query's three streams
 // in flight at once and settles what tier 1 / tier 2 settle (their sums reduced into the wave's LDS row); phase 2 runs
 // rounds in which every lane with an unsettled query searches the grid, one query per lane and round, and adds the
@@ -702,6 +699,7 @@ __global__ __launch_bounds__(STEP_BLOCK, GPSCAL_MULTI_MINW) void icp_step_multi_
     int uni_bpp, int uni_mbpp, int uni_pair0, unsigned *__restrict__ srch_cnt)
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
+    using SL = SumLayout<WEIGHTED>;
     constexpr int NW = STEP_BLOCK / 64;
     __shared__ double wsum[NW][NACC];
     __shared__ double tslab[NW][8][64];
@@ -756,9 +754,8 @@ __global__ __launch_bounds__(STEP_BLOCK, GPSCAL_MULTI_MINW) void icp_step_multi_
                 pr[q] = warm_r2[src_off + i];
             }
         }
-        double acc[NACC];
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+        double t[SL::NT];
+        unsigned n_found = 0;
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             const int i = first + q * STEP_BLOCK + (int)threadIdx.x;
@@ -792,20 +789,22 @@ __global__ __launch_bounds__(STEP_BLOCK, GPSCAL_MULTI_MINW) void icp_step_multi_
                 }
             }
             n_need += (unsigned)__popcll(__ballot(need));
-            if (need) {
-                pend |= 1u << q;
-                continue;
-            }
-            if (!valid) continue;
-            const bool found = ok && B.index() != 0x7fffffff;
-            if (write_nn & 1) {
+            if (need) pend |= 1u << q;
+            const bool found = ok && !need && B.index() != 0x7fffffff;
+            if (valid && !need && (write_nn & 1)) {
                 A.nn_idx[src_off + i] = found ? B.index() : -1;
                 A.nn_sqd[src_off + i] = found ? B.dist2() : INFINITY;
             }
-            if (!found) continue;
-            acc_pair<WEIGHTED>(acc, px, py, pz, nq, B.dist2(), WEIGHTED ? A.wsrc[src_off + i] : 1.0, with_err);
+            n_found += (unsigned)__popcll(__ballot(found));
+            double w = 1.0;
+            if (WEIGHTED) w = valid ? A.wsrc[src_off + i] : 0.0;
+            if (q == 0)
+                pair_terms<WEIGHTED, true>(t, found, px, py, pz, nq, B.dist2(), w, with_err);
+            else
+                pair_terms<WEIGHTED, false>(t, found, px, py, pz, nq, B.dist2(), w, with_err);
         }
-        wave_reduce_acc<NACC>(acc, slab, [&](int k, double v) { wsum[wave][k] = v; });
+        wave_reduce_terms<SL::NT>(t, slab, [&](int k, double v) { wsum[wave][SL::FIRST + k] = v; });
+        if (lane == 0) wsum[wave][SL::COUNT] = (double)n_found;
     }
     // ---- phase 2: rounds of grid searches, one unsettled query per lane and round
     while (__ballot(pend != 0u) != 0ull) {  // wave-uniform
@@ -825,25 +824,25 @@ __global__ __launch_bounds__(STEP_BLOCK, GPSCAL_MULTI_MINW) void icp_step_multi_
         B.init();
         if (act && __float_as_int(wq.w) != 0x7fffffff) B.consider(sqdist(px, py, pz, wq.x, wq.y, wq.z), wq, BestQ::WARM);
         knn_query<BestQ, BALL>(P, A.sorted, A.cell_start, act, px, py, pz, B, diag >> 8);
-        double acc[NACC];
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
-        if (act) {
-            const bool found = B.index() != 0x7fffffff;
-            float4 nq = wq;
-            if (found && B.pos != BestQ::WARM) {
-                nq = A.sorted[B.pos];
-                warm_q[src_off + i] = nq;
-                const float2 r2 = A.pt_r2[tgt_off + B.index()];
-                warm_r2[src_off + i] = (__float_as_uint(r2.x) & 0xffff0000u) | (__float_as_uint(r2.y) >> 16);
-            }
-            if (write_nn & 1) {
-                A.nn_idx[src_off + i] = found ? B.index() : -1;
-                A.nn_sqd[src_off + i] = found ? B.dist2() : INFINITY;
-            }
-            if (found) acc_pair<WEIGHTED>(acc, px, py, pz, nq, B.dist2(), WEIGHTED ? A.wsrc[src_off + i] : 1.0, with_err);
+        const bool found = act && B.index() != 0x7fffffff;
+        float4 nq = wq;
+        if (found && B.pos != BestQ::WARM) {
+            nq = A.sorted[B.pos];
+            warm_q[src_off + i] = nq;
+            const float2 r2 = A.pt_r2[tgt_off + B.index()];
+            warm_r2[src_off + i] = (__float_as_uint(r2.x) & 0xffff0000u) | (__float_as_uint(r2.y) >> 16);
         }
-        wave_reduce_acc<NACC>(acc, slab, [&](int k, double v) { wsum[wave][k] += v; });
+        if (act && (write_nn & 1)) {
+            A.nn_idx[src_off + i] = found ? B.index() : -1;
+            A.nn_sqd[src_off + i] = found ? B.dist2() : INFINITY;
+        }
+        double w = 1.0;
+        if (WEIGHTED) w = act ? A.wsrc[src_off + i] : 0.0;
+        double t[SL::NT];
+        pair_terms<WEIGHTED, true>(t, found, px, py, pz, nq, B.dist2(), w, with_err);
+        wave_reduce_terms<SL::NT>(t, slab, [&](int k, double v) { wsum[wave][SL::FIRST + k] += v; });
+        const unsigned nf = (unsigned)__popcll(__ballot(found));
+        if (lane == 0) wsum[wave][SL::COUNT] += (double)nf;
     }
     if (lane == 0) s_need[wave] = n_need;
     __syncthreads();
