@@ -518,7 +518,7 @@ def main():
                                       ("torch.distributed" if world > 1 else "one rank: no exchange"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "icp_step_kernel (icp_step_multi_kernel from the learnt iteration on)", "avg_launch_ms": kern_ms,
+                         "kernel": "icp_step_kernel", "avg_launch_ms": kern_ms,
                          "algorithmic_bytes_per_launch": abytes,
                          "frac_search": abytes / (float(np.mean(k_search)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "frac_converged": abytes / (float(np.mean(k_conv)) * 1e-3) / 1e9 / HBM_PEAK_GBS,

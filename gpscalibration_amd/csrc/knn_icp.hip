@@ -531,7 +531,7 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
         for (int k = 0; k < SL::NT; ++k) t[k] = 0.0;
     }
     unsigned n_found = 0;  // correspondences of this wave
-    unsigned n_need = 0;  // queries of this wave that took the grid search (what the schedule of a batch is learnt from)
+    unsigned n_need = 0;  // queries of this wave that took the grid search
 
 #pragma unroll 1
     for (int q = 0; q < QPT; ++q) {
@@ -613,12 +613,11 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
     const float4 *__restrict__ nbr, const float2 *__restrict__ pt_r2, const unsigned *__restrict__ cell_start,
     const float *__restrict__ pose32, int *__restrict__ nn_idx, float *__restrict__ nn_sqd,
     float4 *__restrict__ warm_q, unsigned *__restrict__ warm_r2, double *__restrict__ partials, int nblk, int diag,
-    int write_nn, int uni_n, int uni_m, int uni_bpp, int uni_pair0, unsigned *__restrict__ srch_cnt)
+    int write_nn, int uni_n, int uni_m, int uni_bpp, int uni_pair0)
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
     __shared__ double wsum[STEP_BLOCK / 64][NACC];
     __shared__ double tslab[STEP_BLOCK / 64][8][64];  // per-wave transpose slab (4 KiB / wave)
-    __shared__ unsigned s_need[STEP_BLOCK / 64];
 
     const int lb = xcd_remap(blockIdx.x, nblk);
     // A batch of equal-sized scans (uni_n > 0: every source cloud uni_n points, every target cloud uni_m, stored back
@@ -641,230 +640,14 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
         tgt_off = pairs[b].tgt_off;
     }
     const StepArgs A = {src4, wsrc, sorted, nbr, pt_r2, cell_start, nn_idx, nn_sqd, warm_q, warm_r2};
-    const unsigned n_need = step_body<QPT, WEIGHTED, BALL, STEP_BLOCK>(A, pairs[b], pose32 + (size_t)b * 12, first, src_n,
-                                                                       src_off, tgt_off, diag, write_nn, wsum, tslab);
-    if ((threadIdx.x & 63) == 0) s_need[threadIdx.x >> 6] = n_need;
+    step_body<QPT, WEIGHTED, BALL, STEP_BLOCK>(A, pairs[b], pose32 + (size_t)b * 12, first, src_n, src_off, tgt_off, diag,
+                                               write_nn, wsum, tslab);
     __syncthreads();
     if (threadIdx.x < NACC) {
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < STEP_BLOCK / 64; ++w) v += wsum[w][threadIdx.x];
         partials[(size_t)lb * NACC + threadIdx.x] = v;
-    }
-    if (srch_cnt && threadIdx.x == 0) {  // queries of this workgroup that searched: the solve kernel adds them per pair
-        unsigned t = 0;
-#pragma unroll
-        for (int w = 0; w < STEP_BLOCK / 64; ++w) t += s_need[w];
-        srch_cnt[lb] = t;
-    }
-}
-
-struct Pose32 {
-    float r00, r01, r02, tx, r10, r11, r12, ty, r20, r21, r22, tz;
-    __device__ __forceinline__ void load(const float *__restrict__ T)
-    {
-        r00 = T[0]; r01 = T[1]; r02 = T[2]; tx = T[3];
-        r10 = T[4]; r11 = T[5]; r12 = T[6]; ty = T[7];
-        r20 = T[8]; r21 = T[9]; r22 = T[10]; tz = T[11];
-    }
-    // the transform every implementation shares (oracle: explicit fmaf chains)
-    __device__ __forceinline__ void apply(const float4 &s, float &px, float &py, float &pz) const
-    {
-        px = __fmaf_rn(r00, s.x, __fmaf_rn(r01, s.y, __fmaf_rn(r02, s.z, tx)));
-        py = __fmaf_rn(r10, s.x, __fmaf_rn(r11, s.y, __fmaf_rn(r12, s.z, ty)));
-        pz = __fmaf_rn(r20, s.x, __fmaf_rn(r21, s.y, __fmaf_rn(r22, s.z, tz)));
-    }
-};
-
-// The converged iterations' step kernel: QPT queries per lane in two phases.  Phase 1 has every query's three streams
-// in flight at once and settles what tier 1 / tier 2 settle (their sums reduced into the wave's LDS row); phase 2 runs
-// rounds in which every lane with an unsettled query searches the grid, one query per lane and round, and adds the
-// round's sums to the same row -- so no float64 sum is alive during a search and one prologue and (mostly) one
-// reduction serve QPT queries.  Measured in round 2 (branch multi-query-experiment): 37.7 us per converged launch
-// against 48 us for icp_step_kernel, but +11 % while most queries still search (the streams are read twice, a
-// reduction per round); hence it is launched only from the iteration on at which the previous run of the batch had
-// (nearly) stopped searching (gpscal_scan_batch_icp).  A workgroup covers QPT slices of STEP_BLOCK points, i.e. QPT
-// partial-sum slots of the icp_step_kernel layout: it writes its sums to the first and zeros to the others, so the
-// solve kernel needs no second layout.
-#ifndef GPSCAL_MULTI_MINW
-#define GPSCAL_MULTI_MINW 6  // waves per SIMD the register allocation aims at (80 VGPRs; measured with 2 queries per lane)
-#endif
-#ifndef GPSCAL_MULTI_QPT
-#define GPSCAL_MULTI_QPT 2
-#endif
-template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK>
-__global__ __launch_bounds__(STEP_BLOCK, GPSCAL_MULTI_MINW) void icp_step_multi_kernel(
-    const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first, StepArgs A,
-    const float *__restrict__ pose32, double *__restrict__ partials, int nblk, int diag, int write_nn, int uni_n, int uni_m,
-    int uni_bpp, int uni_mbpp, int uni_pair0, unsigned *__restrict__ srch_cnt)
-{
-    constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
-    using SL = SumLayout<WEIGHTED>;
-    constexpr int NW = STEP_BLOCK / 64;
-    __shared__ double wsum[NW][NACC];
-    __shared__ double tslab[NW][8][64];
-    __shared__ unsigned s_need[NW];
-
-    const int lb = xcd_remap(blockIdx.x, nblk);
-    int b, first, src_n, slot0, nslot;
-    long long src_off, tgt_off;
-    if (uni_n > 0) {
-        const int bl = lb / uni_mbpp;
-        b = uni_pair0 + bl;
-        first = (lb - bl * uni_mbpp) * (STEP_BLOCK * QPT);
-        src_n = uni_n;
-        src_off = (long long)b * uni_n;
-        tgt_off = (long long)b * uni_m;
-        slot0 = b * uni_bpp;
-        nslot = uni_bpp;
-    } else {
-        b = __builtin_amdgcn_readfirstlane(blk_pair[lb]);
-        first = __builtin_amdgcn_readfirstlane(blk_first[lb]);
-        src_n = pairs[b].n;
-        src_off = pairs[b].src_off;
-        tgt_off = pairs[b].tgt_off;
-        slot0 = pairs[b].pblk_off;
-        nslot = pairs[b].pblk_cnt;
-    }
-    const PairDesc &P = pairs[b];
-    Pose32 T;
-    T.load(pose32 + (size_t)b * 12);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool with_err = !(write_nn & 2);
-    double *slab = &tslab[wave][0][0];
-    const float4 *__restrict__ src4 = A.src4;
-    float4 *__restrict__ warm_q = A.warm_q;
-    unsigned *__restrict__ warm_r2 = A.warm_r2;
-
-    unsigned pend = 0;  // bit q: query q of this lane still needs the grid search
-    unsigned n_need = 0;
-    {
-        // ---- phase 1: every query's streams in flight, tiers 1 and 2, sums of the settled queries
-        float4 s[QPT], wq[QPT];
-        unsigned pr[QPT];
-#pragma unroll
-        for (int q = 0; q < QPT; ++q) {
-            const int i = first + q * STEP_BLOCK + (int)threadIdx.x;
-            s[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            wq[q] = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
-            pr[q] = 0u;
-            if (i < src_n) {
-                s[q] = src4[src_off + i];
-                wq[q] = warm_q[src_off + i];
-                pr[q] = warm_r2[src_off + i];
-            }
-        }
-        double t[SL::NT];
-        unsigned n_found = 0;
-#pragma unroll
-        for (int q = 0; q < QPT; ++q) {
-            const int i = first + q * STEP_BLOCK + (int)threadIdx.x;
-            const bool valid = i < src_n;
-            const bool ok = valid && finite3(s[q].x, s[q].y, s[q].z);
-            float px, py, pz;
-            T.apply(s[q], px, py, pz);
-            const float ra2 = __uint_as_float(pr[q] & 0xffff0000u), rb2 = __uint_as_float(pr[q] << 16);
-            BestQ B;
-            B.init();
-            bool need = ok;
-            float4 nq = wq[q];
-            if (ok && __float_as_int(wq[q].w) != 0x7fffffff) {
-                const float d0 = sqdist(px, py, pz, wq[q].x, wq[q].y, wq[q].z);
-                B.consider(d0, wq[q], BestQ::WARM);
-                need = !(d0 < ra2);  // tier 1
-                if (need && d0 < rb2) {  // tier 2
-                    const float4 *nb = A.nbr + 4 * (tgt_off + __float_as_int(wq[q].w));
-                    const float4 n0 = nb[0], n1 = nb[1], n2 = nb[2], n3 = nb[3];
-                    B.consider(sqdist(px, py, pz, n0.x, n0.y, n0.z), n0, BestQ::LIST + 0);
-                    B.consider(sqdist(px, py, pz, n1.x, n1.y, n1.z), n1, BestQ::LIST + 1);
-                    B.consider(sqdist(px, py, pz, n2.x, n2.y, n2.z), n2, BestQ::LIST + 2);
-                    B.consider(sqdist(px, py, pz, n3.x, n3.y, n3.z), n3, BestQ::LIST + 3);
-                    need = false;
-                    if (B.pos != BestQ::WARM) {  // one of the four: it becomes the remembered neighbour
-                        nq = nb[B.pos - BestQ::LIST];
-                        warm_q[src_off + i] = nq;
-                        const float2 r2 = A.pt_r2[tgt_off + B.index()];
-                        warm_r2[src_off + i] = (__float_as_uint(r2.x) & 0xffff0000u) | (__float_as_uint(r2.y) >> 16);
-                    }
-                }
-            }
-            n_need += (unsigned)__popcll(__ballot(need));
-            if (need) pend |= 1u << q;
-            const bool found = ok && !need && B.index() != 0x7fffffff;
-            if (valid && !need && (write_nn & 1)) {
-                A.nn_idx[src_off + i] = found ? B.index() : -1;
-                A.nn_sqd[src_off + i] = found ? B.dist2() : INFINITY;
-            }
-            n_found += (unsigned)__popcll(__ballot(found));
-            double w = 1.0;
-            if (WEIGHTED) w = valid ? A.wsrc[src_off + i] : 0.0;
-            if (q == 0)
-                pair_terms<WEIGHTED, true>(t, found, px, py, pz, nq, B.dist2(), w, with_err);
-            else
-                pair_terms<WEIGHTED, false>(t, found, px, py, pz, nq, B.dist2(), w, with_err);
-        }
-        wave_reduce_terms<SL::NT>(t, slab, [&](int k, double v) { wsum[wave][SL::FIRST + k] = v; });
-        if (lane == 0) wsum[wave][SL::COUNT] = (double)n_found;
-    }
-    // ---- phase 2: rounds of grid searches, one unsettled query per lane and round
-    while (__ballot(pend != 0u) != 0ull) {  // wave-uniform
-        const bool act = pend != 0u;
-        const int q = act ? __builtin_ctz(pend) : 0;
-        pend &= pend - 1u;
-        const int i = first + q * STEP_BLOCK + (int)threadIdx.x;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 wq = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
-        if (act) {
-            s = src4[src_off + i];
-            wq = warm_q[src_off + i];
-        }
-        float px, py, pz;
-        T.apply(s, px, py, pz);
-        BestQ B;
-        B.init();
-        if (act && __float_as_int(wq.w) != 0x7fffffff) B.consider(sqdist(px, py, pz, wq.x, wq.y, wq.z), wq, BestQ::WARM);
-        knn_query<BestQ, BALL>(P, A.sorted, A.cell_start, act, px, py, pz, B, diag >> 8);
-        const bool found = act && B.index() != 0x7fffffff;
-        float4 nq = wq;
-        if (found && B.pos != BestQ::WARM) {
-            nq = A.sorted[B.pos];
-            warm_q[src_off + i] = nq;
-            const float2 r2 = A.pt_r2[tgt_off + B.index()];
-            warm_r2[src_off + i] = (__float_as_uint(r2.x) & 0xffff0000u) | (__float_as_uint(r2.y) >> 16);
-        }
-        if (act && (write_nn & 1)) {
-            A.nn_idx[src_off + i] = found ? B.index() : -1;
-            A.nn_sqd[src_off + i] = found ? B.dist2() : INFINITY;
-        }
-        double w = 1.0;
-        if (WEIGHTED) w = act ? A.wsrc[src_off + i] : 0.0;
-        double t[SL::NT];
-        pair_terms<WEIGHTED, true>(t, found, px, py, pz, nq, B.dist2(), w, with_err);
-        wave_reduce_terms<SL::NT>(t, slab, [&](int k, double v) { wsum[wave][SL::FIRST + k] += v; });
-        const unsigned nf = (unsigned)__popcll(__ballot(found));
-        if (lane == 0) wsum[wave][SL::COUNT] += (double)nf;
-    }
-    if (lane == 0) s_need[wave] = n_need;
-    __syncthreads();
-    // the workgroup's sums go to the first of its QPT slots of the icp_step_kernel layout, zeros to the others
-    const int m0 = first / STEP_BLOCK;  // first slot of this workgroup inside the pair
-    if (threadIdx.x < NACC) {
-        double v = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) v += wsum[w][threadIdx.x];
-        partials[(size_t)(slot0 + m0) * NACC + threadIdx.x] = v;
-#pragma unroll
-        for (int k = 1; k < QPT; ++k)
-            if (m0 + k < nslot) partials[(size_t)(slot0 + m0 + k) * NACC + threadIdx.x] = 0.0;
-    }
-    if (srch_cnt && threadIdx.x == 0) {
-        unsigned t = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t += s_need[w];
-        srch_cnt[slot0 + m0] = t;
-#pragma unroll
-        for (int k = 1; k < QPT; ++k)
-            if (m0 + k < nslot) srch_cnt[slot0 + m0 + k] = 0u;
     }
 }
 
@@ -940,17 +723,13 @@ __device__ __forceinline__ void solve_pose(const double (&a)[WEIGHTED ? NACC_WEI
     }
 }
 
-constexpr int ICP_HIST_CAP = 64;  // iterations of a run whose count of searching queries is recorded per pair
-
 // One wave per pair: reduce the pair's block partials in fixed order, solve the
 // rigid transform, compose the pose.
 template <bool WEIGHTED>
 __global__ __launch_bounds__(64) void icp_solve_kernel(const PairDesc *__restrict__ pairs,
                                                         const double *__restrict__ partials,
                                                         double *__restrict__ pose64, float *__restrict__ pose32,
-                                                        double *__restrict__ err_hist, int it, int iters_cap, int pair0,
-                                                        const unsigned *__restrict__ srch_cnt,
-                                                        unsigned *__restrict__ srch_hist, int hist_slot)
+                                                        double *__restrict__ err_hist, int it, int iters_cap, int pair0)
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
     const int b = pair0 + blockIdx.x;
@@ -959,18 +738,14 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const PairDesc *__restric
     double a[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) a[k] = 0.0;
-    double searched = 0.0;  // queries of the pair that took the grid search in this iteration
     for (int j = lane; j < P.pblk_cnt; j += 64) {
         const double *pp = partials + (size_t)(P.pblk_off + j) * NACC;
 #pragma unroll
         for (int k = 0; k < NACC; ++k) a[k] += pp[k];
-        if (hist_slot >= 0) searched += (double)srch_cnt[P.pblk_off + j];
     }
 #pragma unroll
     for (int k = 0; k < NACC; ++k) a[k] = wave_sum(a[k]);
-    if (hist_slot >= 0) searched = wave_sum(searched);
     if (lane != 0) return;  // wave_sum leaves the totals in every lane
-    if (hist_slot >= 0) srch_hist[(size_t)b * ICP_HIST_CAP + hist_slot] = (unsigned)searched;
     solve_pose<WEIGHTED, false>(a, pose64 + (size_t)b * 16, pose32 + (size_t)b * 12,
                                 err_hist ? err_hist + (size_t)b * iters_cap + it : nullptr);
 }
@@ -1467,22 +1242,6 @@ struct gpscal_scan_batch {
     bool weighted = false;
     int qpt = 1, nblk = 0, diag = 0;
     int step_block = 128;  // threads per workgroup of icp_step_kernel (128 or 256, by batch size)
-    // The schedule of a run: iterations [0, sched_k) since set_pose run icp_step_kernel, the later ones
-    // icp_step_multi_kernel (two queries per lane, built for converged iterations).  sched_k is learnt from the
-    // previous run of the batch from a fresh pose: the solve kernel records how many queries of every pair searched in
-    // every iteration, the history comes back asynchronously, and the switch is put behind the last iteration in which
-    // multi_below of the queries (or more) searched.  Until a history is known nothing is switched.
-    static constexpr int MULTI_QPT = GPSCAL_MULTI_QPT;
-    float multi_below = 0.01f;
-    int sched_k[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};  // per chain
-    long long iters_done = 0;  // iterations since set_pose
-    DevBuf<int> mblk_pair, mblk_first;
-    int nmblk = 0, uni_mbpp = 0, chain_mblk[9] = {};
-    DevBuf<unsigned> srch_cnt, srch_hist;
-    unsigned *h_hist = nullptr;  // pinned copy of srch_hist
-    hipEvent_t hist_ev = nullptr;
-    bool hist_pending = false;
-    int hist_iters = 0;
     bool persistent = false;  // small batch: all iterations of a run in ONE launch (icp_persistent_kernel)
     DevBuf<IcpCtl> ctl;
     int uni_n = 0, uni_m = 0, uni_bpp = 0;  // equal-sized scans stored back to back: workgroup slices by arithmetic
@@ -1502,8 +1261,7 @@ struct gpscal_scan_batch {
     // captured graphs by iteration count (callers that alternate between two counts keep both)
     static constexpr int NGRAPH = 4;
     hipGraphExec_t graphs[NGRAPH] = {};
-    long long graph_iters[NGRAPH] = {};  // key: iterations, error history wanted, fresh run ...
-    int graph_ks[NGRAPH][8] = {};        // ... and every chain's switch point
+    long long graph_iters[NGRAPH] = {};  // key: iterations, error history wanted
     unsigned graph_used[NGRAPH] = {}, graph_clock = 0;
     void drop_graphs()
     {
@@ -1522,11 +1280,6 @@ struct gpscal_scan_batch {
     hipEvent_t chain_ev[MAX_CHAINS] = {};
     ~gpscal_scan_batch()
     {
-        if (hist_ev) {
-            (void)hipEventSynchronize(hist_ev);
-            (void)hipEventDestroy(hist_ev);
-        }
-        if (h_hist) (void)hipHostFree(h_hist);
         drop_graphs();
         if (tgt && !borrowed) delete tgt;
     }
@@ -1675,19 +1428,6 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
         P.pblk_cnt = (int)bp.size() - P.pblk_off;
     }
     B->nblk = (int)bp.size();
-    // the multi-query kernel's workgroups: MULTI_QPT slices of step_block points each
-    std::vector<int> mp, mf;
-    for (int b = 0; b < np; ++b)
-        for (int f = 0; f < B->hpairs[b].n; f += B->step_block * gpscal_scan_batch::MULTI_QPT) {
-            mp.push_back(b);
-            mf.push_back(f);
-        }
-    B->nmblk = (int)mp.size();
-    // Small batches keep one kernel for every iteration (the switch pays only where the launches are throughput-bound, and
-    // a batch without it gives the same bits in every run, its first included).
-    if (B->total_n < (1ll << 20)) B->multi_below = 0.f;
-    if (const char *e = getenv("GPSCAL_ICP_MULTI_BELOW")) B->multi_below = (float)atof(e);
-    if (B->qpt != 1) B->multi_below = 0.f;  // (the tuning knob GPSCAL_QPT=4 runs icp_step_kernel alone)
     // GPSCAL_ICP_PERSISTENT=1: a batch whose step grid is resident all at once runs the iterations of a run in ONE
     // launch (icp_persistent_kernel) instead of the captured graph.  Off by default: measured on one 65 536-point
     // pair it is no faster (33.3 k against 35.1 k iterations/s) -- the run is the sum of the step's own dependent
@@ -1709,8 +1449,6 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
         B->uni_n = uni ? B->hpairs[0].n : 0;
         B->uni_m = uni ? B->hpairs[0].m : 0;
         B->uni_bpp = uni ? B->hpairs[0].pblk_cnt : 0;
-        const int mper = B->step_block * gpscal_scan_batch::MULTI_QPT;
-        B->uni_mbpp = uni ? (B->hpairs[0].n + mper - 1) / mper : 0;
     }
     // chains: contiguous groups of pairs with (nearly) equal block counts; small batches keep one
     {
@@ -1727,13 +1465,6 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
             B->chain_pair[c] = c == want ? np : p;
             B->chain_blk[c] = c == want ? B->nblk : (p < np ? B->hpairs[p].pblk_off : B->nblk);
         }
-        {  // the same chains in multi-query workgroups
-            int m = 0;
-            for (int c = 0; c <= want; ++c) {
-                while (m < B->nmblk && mp[m] < B->chain_pair[c]) ++m;
-                B->chain_mblk[c] = c == want ? B->nmblk : m;
-            }
-        }
         static_assert(gpscal_scan_batch::MAX_CHAINS <= gpscal_ctx::MAX_SIDE, "side streams");
         for (int c = 1; c < want; ++c) {  // the context's side streams: created once, on first use
             if (!ctx->side_stream[c]) GPSCAL_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream[c], hipStreamNonBlocking));
@@ -1748,16 +1479,6 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
         GPSCAL_HIP(ctx, hipMemcpyAsync(B->blk_pair.p, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice, ctx->stream));
         GPSCAL_HIP(ctx, hipMemcpyAsync(B->blk_first.p, bf.data(), sizeof(int) * bf.size(), hipMemcpyHostToDevice, ctx->stream));
     }
-    GPSCAL_HIP(ctx, B->mblk_pair.alloc_async(std::max<size_t>(mp.size(), 1), ctx->stream));
-    GPSCAL_HIP(ctx, B->mblk_first.alloc_async(std::max<size_t>(mf.size(), 1), ctx->stream));
-    if (!mp.empty()) {
-        GPSCAL_HIP(ctx, hipMemcpyAsync(B->mblk_pair.p, mp.data(), sizeof(int) * mp.size(), hipMemcpyHostToDevice, ctx->stream));
-        GPSCAL_HIP(ctx, hipMemcpyAsync(B->mblk_first.p, mf.data(), sizeof(int) * mf.size(), hipMemcpyHostToDevice, ctx->stream));
-    }
-    GPSCAL_HIP(ctx, B->srch_cnt.alloc_async((size_t)std::max(B->nblk, 1), ctx->stream));
-    GPSCAL_HIP(ctx, B->srch_hist.alloc_async((size_t)np * ICP_HIST_CAP, ctx->stream));
-    GPSCAL_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&B->h_hist), sizeof(unsigned) * (size_t)np * ICP_HIST_CAP));
-    GPSCAL_HIP(ctx, hipEventCreateWithFlags(&B->hist_ev, hipEventDisableTiming));
     GPSCAL_HIP(ctx, B->pairs.alloc_async(np, ctx->stream));
     GPSCAL_HIP(ctx, hipMemcpyAsync(B->pairs.p, B->hpairs.data(), sizeof(PairDesc) * np, hipMemcpyHostToDevice, ctx->stream));
     B->weighted = w != nullptr;
@@ -1845,7 +1566,6 @@ extern "C" int gpscal_scan_batch_set_pose(gpscal_scan_batch *B, const double *T0
     // that a run never profits from correspondences an earlier run computed
     hipLaunchKernelGGL(fill_warm_kernel, dim3(div_up(std::max<long long>(B->total_n, 1), BLOCK)), dim3(BLOCK), 0,
                        ctx->stream, B->warm_q.p, B->warm_r2.p, B->total_n);
-    B->iters_done = 0;
     GPSCAL_HIP(ctx, hipGetLastError());
     return GPSCAL_OK;
 }
@@ -1868,34 +1588,9 @@ extern "C" int gpscal_debug_stats(unsigned long long *out, int n)
 // step -> solve -> step ...: while one group's solve kernel (one wave per pair, ~9 us of dependent float64
 // arithmetic) runs, the other groups' step kernels keep the chip busy.  Chain c = pairs [chain_pair[c],
 // chain_pair[c+1]) = blocks [chain_blk[c], chain_blk[c+1]); partial-sum slots stay global.
-static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st, bool want_err = true, bool multi = false)
+static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st, bool want_err = true)
 {
     GridSet &G = *B->tgt;
-    if (multi) {  // the converged iterations' kernel (two queries per lane), same chains in its own workgroups
-        const int m0 = c < 0 ? 0 : B->chain_mblk[c], nm = (c < 0 ? B->nmblk : B->chain_mblk[c + 1]) - m0;
-        if (nm <= 0) return;
-        const StepArgs A = {B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p, G.cell_start,
-                            B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p};
-#define MULTI(W, BALL, BS)                                                                                           \
-    hipLaunchKernelGGL((icp_step_multi_kernel<gpscal_scan_batch::MULTI_QPT, W, BALL, BS>), dim3(nm), dim3(BS), 0, st, \
-                       B->pairs.p, B->mblk_pair.p + m0, B->mblk_first.p + m0, A, B->pose32.p, B->partials.p, nm,      \
-                       B->ball_r << 8, (last ? 1 : 0) | (want_err ? 0 : 2), B->uni_n, B->uni_m, B->uni_bpp,           \
-                       B->uni_mbpp, c < 0 ? 0 : B->chain_pair[c], B->srch_cnt.p)
-#define MULTI_BS(W, BALL)                                          \
-    do {                                                           \
-        if (B->step_block == 256) MULTI(W, BALL, 256);             \
-        else MULTI(W, BALL, 128);                                  \
-    } while (0)
-        const bool mball = B->ball_r > 0;
-        if (B->weighted) {
-            if (mball) MULTI_BS(true, true); else MULTI_BS(true, false);
-        } else {
-            if (mball) MULTI_BS(false, true); else MULTI_BS(false, false);
-        }
-#undef MULTI_BS
-#undef MULTI
-        return;
-    }
     // c < 0: the whole batch in one launch (profiling mode: the launch the roofline is quoted for)
     const int b0 = c < 0 ? 0 : B->chain_blk[c], nb = (c < 0 ? B->nblk : B->chain_blk[c + 1]) - b0;
     if (nb <= 0) return;
@@ -1910,8 +1605,7 @@ static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st, 
                        B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p,                              \
                        B->partials.p + (size_t)b0 * (B->weighted ? NACC_WEIGHTED : NACC_PLAIN), nb,                  \
                        (B->diag & 0xff) | (B->ball_r << 8), (last ? 1 : 0) | (want_err ? 0 : 2), B->uni_n, B->uni_m,   \
-                       B->uni_bpp,                                                                                  \
-                       c < 0 ? 0 : B->chain_pair[c], B->srch_cnt.p + b0)
+                       B->uni_bpp, c < 0 ? 0 : B->chain_pair[c])
     // the ball search costs the kernel a wave of occupancy: its own instantiation, chosen per batch
     const bool ball = B->ball_r > 0;
     if (B->weighted) {
@@ -1923,49 +1617,16 @@ static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st, 
 #undef STEP_BS
 }
 
-// hist_slot >= 0: the solve kernel also records how many queries of every pair searched (schedule learning)
-static void launch_solve(gpscal_scan_batch *B, int it, int c, hipStream_t st, int hist_slot = -1)
+static void launch_solve(gpscal_scan_batch *B, int it, int c, hipStream_t st)
 {
     const int p0 = c < 0 ? 0 : B->chain_pair[c], np = (c < 0 ? B->npairs : B->chain_pair[c + 1]) - p0;
     if (np <= 0) return;
-    if (hist_slot >= ICP_HIST_CAP) hist_slot = -1;
     if (B->weighted)
         hipLaunchKernelGGL(icp_solve_kernel<true>, dim3(np), dim3(64), 0, st, B->pairs.p, B->partials.p, B->pose64.p,
-                           B->pose32.p, B->err_hist.p, it, B->err_cap, p0, B->srch_cnt.p, B->srch_hist.p, hist_slot);
+                           B->pose32.p, B->err_hist.p, it, B->err_cap, p0);
     else
         hipLaunchKernelGGL(icp_solve_kernel<false>, dim3(np), dim3(64), 0, st, B->pairs.p, B->partials.p, B->pose64.p,
-                           B->pose32.p, B->err_hist.p, it, B->err_cap, p0, B->srch_cnt.p, B->srch_hist.p, hist_slot);
-}
-
-// A finished fresh run's history of searching queries, if it has arrived: the switch to the multi-query kernel goes
-// behind the last iteration in which multi_below of the batch's queries (or more) searched.
-static void learn_schedule(gpscal_scan_batch *B)
-{
-    if (!B->hist_pending || hipEventQuery(B->hist_ev) != hipSuccess) {
-        (void)hipGetLastError();  // hipErrorNotReady is not an error
-        return;
-    }
-    B->hist_pending = false;
-    for (int c = 0; c < B->nchains; ++c) {  // every chain switches by its own pairs
-        B->sched_k[c] = 0x7fffffff;
-        if (!(B->multi_below > 0.f)) continue;
-        double n_chain = 0;
-        for (int b = B->chain_pair[c]; b < B->chain_pair[c + 1]; ++b) n_chain += B->hpairs[b].n;
-        if (!(n_chain > 0)) continue;
-        int k = 0;
-        for (int it = 0; it < B->hist_iters; ++it) {
-            double tot = 0;
-            for (int b = B->chain_pair[c]; b < B->chain_pair[c + 1]; ++b) tot += B->h_hist[(size_t)b * ICP_HIST_CAP + it];
-            if (tot >= (double)B->multi_below * n_chain) k = it + 1;
-        }
-        // (still searching at the end of what is known: nothing is known about later iterations)
-        if (k < B->hist_iters) B->sched_k[c] = k;
-    }
-    if (getenv("GPSCAL_SCHED_DEBUG")) {
-        fprintf(stderr, "icp schedule learnt from %d iterations:", B->hist_iters);
-        for (int c = 0; c < B->nchains; ++c) fprintf(stderr, " chain %d -> %d", c, B->sched_k[c]);
-        fprintf(stderr, "\n");
-    }
+                           B->pose32.p, B->err_hist.p, it, B->err_cap, p0);
 }
 
 extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_out, double *mean_err,
@@ -1981,22 +1642,6 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
         GPSCAL_HIP(ctx, B->err_hist.alloc_async((size_t)np * iters, ctx->stream));
         B->err_cap = iters;
     }
-    learn_schedule(B);
-    const long long start = B->iters_done;
-    const bool fresh = start == 0;  // the run starts at a new pose: its history is what the schedule is learnt from
-    // iterations [0, ks[c]) of this call run icp_step_kernel on chain c, the rest icp_step_multi_kernel
-    int ks[gpscal_scan_batch::MAX_CHAINS];
-    int ks_min = iters, ks_max = 0;
-    for (int c = 0; c < gpscal_scan_batch::MAX_CHAINS; ++c) {
-        ks[c] = iters;
-        if (c < B->nchains && B->multi_below > 0.f && B->sched_k[c] != 0x7fffffff)
-            ks[c] = (int)std::min<long long>(std::max<long long>((long long)B->sched_k[c] - start, 0), iters);
-        if (c < B->nchains) {
-            ks_min = std::min(ks_min, ks[c]);
-            ks_max = std::max(ks_max, ks[c]);
-        }
-    }
-    B->iters_done += iters;
     if (step_ms) {
         // profiling mode: every correspondence launch bracketed by HIP events
         std::vector<hipEvent_t> ev((size_t)iters * 2);
@@ -2006,15 +1651,9 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
             hipLaunchKernelGGL(stat_set_iter_kernel, dim3(1), dim3(1), 0, ctx->stream, std::min(it, STAT_ITERS - 1));
 #endif
             GPSCAL_HIP(ctx, hipEventRecord(ev[2 * it], ctx->stream));
-            // whole-batch launches (the launch the roofline is quoted for) while all chains run the same kernel; in the
-            // iterations between the first and the last chain's switch every chain gets its own launch, as in the graph
-            if (it < ks_min || it >= ks_max) {
-                launch_step(B, it == iters - 1, -1, ctx->stream, want_err, it >= ks_max);
-            } else {
-                for (int c = 0; c < B->nchains; ++c) launch_step(B, it == iters - 1, c, ctx->stream, want_err, it >= ks[c]);
-            }
+            launch_step(B, it == iters - 1, -1, ctx->stream, want_err);  // whole batch (the launch the roofline is quoted for)
             GPSCAL_HIP(ctx, hipEventRecord(ev[2 * it + 1], ctx->stream));
-            launch_solve(B, it, -1, ctx->stream, fresh ? it : -1);
+            launch_solve(B, it, -1, ctx->stream);
         }
         GPSCAL_HIP(ctx, hipGetLastError());
         GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2040,11 +1679,11 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
 #undef PERSIST
         GPSCAL_HIP(ctx, hipGetLastError());
     } else if (iters > 0) {
-        // a graph per (iteration count, error history wanted, fresh run, the chains' switch points)
-        const long long gkey = ((long long)iters * 2 + (want_err ? 1 : 0)) * 2 + (fresh ? 1 : 0);
+        // a graph per (iteration count, error history wanted)
+        const long long gkey = (long long)iters * 2 + (want_err ? 1 : 0);
         int slot = -1;
         for (int k = 0; k < gpscal_scan_batch::NGRAPH; ++k)
-            if (B->graphs[k] && B->graph_iters[k] == gkey && !memcmp(B->graph_ks[k], ks, sizeof ks)) slot = k;
+            if (B->graphs[k] && B->graph_iters[k] == gkey) slot = k;
         if (slot < 0) {
             slot = 0;  // an empty slot, else the least recently used one
             for (int k = 0; k < gpscal_scan_batch::NGRAPH; ++k) {
@@ -2068,8 +1707,8 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
             for (int it = 0; it < iters; ++it)
                 for (int c = 0; c < B->nchains; ++c) {
                     hipStream_t st = c == 0 ? ctx->stream : B->chain_stream[c];
-                    launch_step(B, it == iters - 1, c, st, want_err, it >= ks[c]);
-                    launch_solve(B, it, c, st, fresh ? it : -1);
+                    launch_step(B, it == iters - 1, c, st, want_err);
+                    launch_solve(B, it, c, st);
                 }
             for (int c = 1; c < B->nchains; ++c) {
                 GPSCAL_HIP(ctx, hipEventRecord(B->chain_ev[c], B->chain_stream[c]));
@@ -2079,18 +1718,9 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
             GPSCAL_HIP(ctx, hipGraphInstantiate(&B->graphs[slot], g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
             B->graph_iters[slot] = gkey;
-            memcpy(B->graph_ks[slot], ks, sizeof ks);
         }
         B->graph_used[slot] = ++B->graph_clock;
         GPSCAL_HIP(ctx, hipGraphLaunch(B->graphs[slot], ctx->stream));
-    }
-    if (fresh && iters > 0 && !(B->persistent && !step_ms)) {
-        // the run's history of searching queries comes back behind it, without a wait (learn_schedule polls the event)
-        GPSCAL_HIP(ctx, hipMemcpyAsync(B->h_hist, B->srch_hist.p, sizeof(unsigned) * (size_t)np * ICP_HIST_CAP,
-                                       hipMemcpyDeviceToHost, ctx->stream));
-        GPSCAL_HIP(ctx, hipEventRecord(B->hist_ev, ctx->stream));
-        B->hist_pending = true;
-        B->hist_iters = std::min(iters, ICP_HIST_CAP);
     }
     bool sync = false;
     if (T_out) {

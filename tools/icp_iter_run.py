@@ -12,7 +12,7 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 tg, to, sr, so, _ = synth.scan_batch(npairs, n)
 ctx = Context(0)
 sb = ctx.scan_batch(torch.from_numpy(tg).cuda(), to, torch.from_numpy(sr).cuda(), so)
-sb.icp(iters, want_err=True)  # a first run from the fresh pose: the batch learns its schedule from it
+sb.icp(iters, want_err=True)  # a first run (graph capture, caches warm)
 sb.set_pose(None)
 sb.icp(iters, want_err=True, profile=True)
 ctx.sync()
