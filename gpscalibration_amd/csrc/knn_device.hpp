@@ -247,7 +247,7 @@ struct __attribute__((packed, aligned(4))) CellQuad {
 
 // Candidates [s, e) of `sorted`, scanned by the lane itself with four 16-byte
 // gathers in flight.
-template <class BT>
+template <class BT, bool SAME_CLOUD = false>
 __device__ __forceinline__ void scan_short(BT &B, bool act, const float4 *__restrict__ sorted, unsigned s, unsigned e,
                                            float px, float py, float pz)
 {
@@ -265,10 +265,23 @@ __device__ __forceinline__ void scan_short(BT &B, bool act, const float4 *__rest
     if (GPSCAL_SCAN_DIAG == 1) return;
     if (GPSCAL_SCAN_DIAG == 2) e = min(e, s + 1u);
 #endif
+    // Addresses.  SAME_CLOUD (the caller's lanes all search one level of one cloud, < 2^25 points): one SIGNED 32-bit
+    // byte offset per group, relative to the run of the wave's first active lane (other lanes' runs lie on either side
+    // of it, at most 2^25 points away whatever the batch's size); the four loads of a group share one 64-bit address
+    // (+ immediates) instead of four.  Otherwise (lanes in different clouds of a set) positions are addressed in full.
+    const unsigned p0 = SAME_CLOUD ? __builtin_amdgcn_readfirstlane(s) : 0u;
+    const char *base = reinterpret_cast<const char *>(sorted + p0);
+    auto ld = [&](unsigned jj, unsigned k) -> float4 {
+        if constexpr (SAME_CLOUD)
+            return *reinterpret_cast<const float4 *>(base + (ptrdiff_t)((int)(jj - p0) * 16) + 16 * (int)k);
+        else
+            return sorted[jj + k];
+    };
     unsigned j = s;
     // full groups of four: no clamps, no per-candidate guards
     for (; j + 4 <= e; j += 4) {
-        const float4 c0 = sorted[j], c1 = sorted[j + 1], c2 = sorted[j + 2], c3 = sorted[j + 3];
+        const unsigned off = j;
+        const float4 c0 = ld(off, 0), c1 = ld(off, 1), c2 = ld(off, 2), c3 = ld(off, 3);
         B.consider(sqdist(px, py, pz, c0.x, c0.y, c0.z), c0, j);
         B.consider(sqdist(px, py, pz, c1.x, c1.y, c1.z), c1, j + 1);
         B.consider(sqdist(px, py, pz, c2.x, c2.y, c2.z), c2, j + 2);
@@ -276,9 +289,9 @@ __device__ __forceinline__ void scan_short(BT &B, bool act, const float4 *__rest
     }
     if (j < e) {  // the last one to three, still fetched together
         const unsigned last = e - 1;
-        const float4 c0 = sorted[j];
-        const float4 c1 = sorted[min(j + 1, last)];
-        const float4 c2 = sorted[min(j + 2, last)];
+        const float4 c0 = ld(j, 0);
+        const float4 c1 = ld(min(j + 1, last), 0);
+        const float4 c2 = ld(min(j + 2, last), 0);
         B.consider(sqdist(px, py, pz, c0.x, c0.y, c0.z), c0, j);
         if (j + 1 < e) B.consider(sqdist(px, py, pz, c1.x, c1.y, c1.z), c1, j + 1);
         if (j + 2 < e) B.consider(sqdist(px, py, pz, c2.x, c2.y, c2.z), c2, j + 2);
@@ -297,12 +310,12 @@ __device__ __forceinline__ float readlane_f(float v, int l)
 // runs are scanned per lane.  A long run (a dense or coarse cell) is scanned by the
 // whole wave for its owner: 64 consecutive candidates per step, one coalesced 1 KiB
 // load instead of 64 dependent gathers by one lane, then a DPP arg-min.
-template <class BT>
+template <class BT, bool SAME_CLOUD = false>
 __device__ __forceinline__ void scan_runs(BT &B, bool act, const float4 *__restrict__ sorted, unsigned s, unsigned e,
                                           float px, float py, float pz)
 {
     if constexpr (!BT::COOP) {
-        scan_short(B, act, sorted, s, e, px, py, pz);
+        scan_short<BT, SAME_CLOUD>(B, act, sorted, s, e, px, py, pz);
     } else {
         bool lng = act && (e - s) > COOP_MIN;
         unsigned long long m = __ballot(lng);
@@ -310,7 +323,7 @@ __device__ __forceinline__ void scan_runs(BT &B, bool act, const float4 *__restr
             m = 0ull;
             lng = false;
         }
-        scan_short(B, act && !lng, sorted, s, e, px, py, pz);
+        scan_short<BT, SAME_CLOUD>(B, act && !lng, sorted, s, e, px, py, pz);
         const int lane = threadIdx.x & 63;
         while (m) {  // wave-uniform
             const int owner = __builtin_ctzll(m);
@@ -326,7 +339,8 @@ __device__ __forceinline__ void scan_runs(BT &B, bool act, const float4 *__restr
             for (unsigned j0 = ss; j0 < ee; j0 += 64) {
                 const unsigned j = j0 + lane;
                 if (j < ee) {
-                    const float4 c = sorted[j];
+                    const float4 c = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sorted + ss) +
+                                                                       (size_t)((j - ss) << 4));
                     const float d2 = sqdist(qx, qy, qz, c.x, c.y, c.z);
                     const int ci = __float_as_int(c.w);
                     if (d2 < bd || (d2 == bd && ci < bi)) {
@@ -380,7 +394,7 @@ struct CellGeo {
 // One level of the fine -> coarse search: the 3x3x3 block of cells around the query.  Rows
 // (fixed y,z; x-1..x+1 contiguous in memory) and then single cells are skipped when their
 // nearest face is already farther than the k-th best.  Wave-uniform.
-template <class BT>
+template <class BT, bool SAME_CLOUD = false>
 __device__ __forceinline__ void block3_level(const GridDesc &G, const CellGeo &C, const float4 *__restrict__ sorted,
                                              const unsigned *__restrict__ cell_start, bool act, float px, float py,
                                              float pz, BT &B)
@@ -414,8 +428,9 @@ __device__ __forceinline__ void block3_level(const GridDesc &G, const CellGeo &C
         if ((lanemask >> r) & 1u) {
             const int kz = r / 3, ky = r - 3 * kz;
             const int zz = C.cz + (kz == 0 ? 0 : (kz == 1 ? -1 : 1)), yy = C.cy + (ky == 0 ? 0 : (ky == 1 ? -1 : 1));
-            const long long row = G.cell_base + ((long long)zz * G.ny + yy) * G.nx + C.cx;
-            q = *reinterpret_cast<const CellQuad *>(cell_start + row - 1);
+            // a level has < 2^25 cells: the row's offset inside the level in 32 bits, behind a scalar base
+            const unsigned rel = (unsigned)((zz * G.ny + yy) * G.nx + C.cx) * 4u;
+            q = *reinterpret_cast<const CellQuad *>(reinterpret_cast<const char *>(cell_start + G.cell_base - 1) + (size_t)rel);
         }
         return q;
     };
@@ -439,7 +454,7 @@ __device__ __forceinline__ void block3_level(const GridDesc &G, const CellGeo &C
         // only tightens.
         const bool pl0 = pass && c0 < c1 && (rb2 + bxl * bxl) * 0.99999f <= B.worst();
         const bool pr0 = pass && c2 < c3 && (rb2 + bxr * bxr) * 0.99999f <= B.worst();
-        scan_runs(B, pass, sorted, pl0 ? c0 : c1, pr0 ? c3 : c2, px, py, pz);
+        scan_runs<BT, SAME_CLOUD>(B, pass, sorted, pl0 ? c0 : c1, pr0 ? c3 : c2, px, py, pz);
     }
 }
 
@@ -577,11 +592,12 @@ __device__ __forceinline__ void ball_level(const GridDesc &G, const CellGeo &C, 
                 // the cells of px -+ hw bracket every point within hw of px
                 const float hw = sqrtf(w - rb2) * 1.00001f + mg;
                 const int x0 = cell_coord(px - hw, G.ox, G.inv_h, G.nx), x1 = cell_coord(px + hw, G.ox, G.inv_h, G.nx);
-                const unsigned *row = cell_start + (G.cell_base + ((long long)zz * G.ny + yy) * G.nx);
-                s = row[x0];
-                e = row[x1 + 1];
+                const char *lv = reinterpret_cast<const char *>(cell_start + G.cell_base);  // scalar base, 32-bit offsets
+                const unsigned row = (unsigned)((zz * G.ny + yy) * G.nx);
+                s = *reinterpret_cast<const unsigned *>(lv + (size_t)((row + (unsigned)x0) * 4u));
+                e = *reinterpret_cast<const unsigned *>(lv + (size_t)((row + (unsigned)x1 + 1u) * 4u));
             }
-            scan_runs(B, pass, sorted, s, e, px, py, pz);
+            scan_runs<BT, true>(B, pass, sorted, s, e, px, py, pz);
         }
     }
 }
@@ -657,7 +673,7 @@ __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__res
                 if (!BT::COOP && slab)  // latency-bound callers hand in a wave-private slab (block3_level_flat)
                     block3_level_flat(G, C, sorted, cell_start, a, px, py, pz, B, slab);
                 else
-                    block3_level(G, C, sorted, cell_start, a, px, py, pz, B);
+                    block3_level<BT, true>(G, C, sorted, cell_start, a, px, py, pz, B);
             } else {
                 ball_level(G, C, sorted, cell_start, a, px, py, pz, B, ball_r);
             }

@@ -390,12 +390,8 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
 // for small ones, where the launch is latency-bound and the solve kernel's sum over the workgroups' partial sums is
 // on the critical path (one 65 536-point pair: 33.4 k iterations/s with 128 threads, 35.8 k with 256).
 
-// The work of one workgroup of the step: its slice of the pair's grouped source (QPT batches of STEP_BLOCK points from
-// `first`) through transform, certificates and search; leaves every wave's sums in wsum[wave][0 .. NACC) (the caller
-// synchronises the workgroup and adds them).  T: the pair's float32 pose (12 values).  Shared by icp_step_kernel
-// (one launch per iteration) and icp_persistent_kernel (all iterations of small batches in one launch).
-// ---- the sums of one iteration.  Both step kernels are bound by the issue rate of vector instructions (SQ counters,
-// round 3: 80 % of the issue slots in the searching iterations, 91 % in the converged ones), so the sums are written
+// ---- the sums of one iteration.  The step kernel issues vector instructions in 80 % of its cycles while it searches
+// and in 91 % of them in a converged launch (SQ counters, round 3), so the sums are written
 // for instruction count: a lane without a correspondence contributes zeros through zeroed INPUTS (straight-line
 // code, no masked block), products enter by one fma, the number of correspondences is counted by ballot on the
 // scalar unit instead of a 17th float64 sum, and sqrt((double)d2) is a float32 rsq with one float64 Newton step.
@@ -491,6 +487,10 @@ __device__ __forceinline__ void wave_reduce_terms(const double *t, double *__res
     }
 }
 
+// The work of one workgroup of the step: its slice of the pair's grouped source (QPT batches of STEP_BLOCK points from
+// `first`) through transform, certificates and search; leaves every wave's sums in wsum[wave][0 .. NACC) (the caller
+// synchronises the workgroup and adds them).  T: the pair's float32 pose (12 values).  Shared by icp_step_kernel
+// (one launch per iteration) and icp_persistent_kernel (all iterations of small batches in one launch).
 struct StepArgs {
     const float4 *__restrict__ src4;
     const double *__restrict__ wsrc;
@@ -1136,6 +1136,8 @@ int build_grids_multi(gpscal_ctx *ctx, int nsrc, const GridSource *src, int stri
             PairDesc &P = gs.hpairs[b];
             P.tgt_off = rel[b];
             P.m = (int)(rel[b + 1] - rel[b]);
+            if (P.m >= (1 << 27))  // scan_short addresses a level's points by signed 32-bit byte offsets
+                return fail(ctx, GPSCAL_ERANGE, "cloud too large (2^27 points or more)");
             float mn[3], mx[3];
             for (int a = 0; a < 3; ++a) {
                 mn[a] = ord2f(hbk[b * 6 + a]);
