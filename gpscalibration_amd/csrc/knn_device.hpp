@@ -78,10 +78,14 @@ __device__ __forceinline__ bool finite3(float x, float y, float z)
 }
 
 // The squared distance every implementation shares (oracle: orc_sqdist).
+typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz)
 {
-    float dx = ax - bx, dy = ay - by, dz = az - bz;
-    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+    // x and y are subtracted as one packed operation (v_pk_add_f32: the same IEEE subtraction, half the issue slots)
+    const float2v a = {ax, ay}, b = {bx, by};
+    const float2v d = a - b;
+    const float dz = az - bz;
+    return __fmaf_rn(dz, dz, __fmaf_rn(d.y, d.y, __fmul_rn(d.x, d.x)));
 }
 
 // XCD-aware block remap (cdna_hip_programming.md T1, bijective form): logical
@@ -289,9 +293,10 @@ __device__ __forceinline__ void scan_short(BT &B, bool act, const float4 *__rest
     }
     if (j < e) {  // the last one to three, still fetched together
         const unsigned last = e - 1;
+        // (SAME_CLOUD: the two entries behind a run's end are read unclamped -- build_grids pads the array -- and not considered)
         const float4 c0 = ld(j, 0);
-        const float4 c1 = ld(min(j + 1, last), 0);
-        const float4 c2 = ld(min(j + 2, last), 0);
+        const float4 c1 = SAME_CLOUD ? ld(j, 1) : ld(min(j + 1, last), 0);
+        const float4 c2 = SAME_CLOUD ? ld(j, 2) : ld(min(j + 2, last), 0);
         B.consider(sqdist(px, py, pz, c0.x, c0.y, c0.z), c0, j);
         if (j + 1 < e) B.consider(sqdist(px, py, pz, c1.x, c1.y, c1.z), c1, j + 1);
         if (j + 2 < e) B.consider(sqdist(px, py, pz, c2.x, c2.y, c2.z), c2, j + 2);

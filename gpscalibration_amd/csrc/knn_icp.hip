@@ -1175,7 +1175,8 @@ int build_grids_multi(gpscal_ctx *ctx, int nsrc, const GridSource *src, int stri
                                   : gs.cell_start_buf.alloc((size_t)cells + 1 + 8));
         GPSCAL_HIP(ctx, hipMemsetAsync(gs.cell_start_buf.p, 0, sizeof(unsigned) * ((size_t)cells + 9), ctx->stream));
         gs.cell_start = gs.cell_start_buf.p + 4;
-        GPSCAL_HIP(ctx, gs.pooled ? gs.sorted.alloc_async((size_t)sorted_total, ctx->stream) : gs.sorted.alloc((size_t)sorted_total));
+        // (+4: scan_short reads up to two entries behind a run's end without looking at them)
+        GPSCAL_HIP(ctx, gs.pooled ? gs.sorted.alloc_async((size_t)sorted_total + 4, ctx->stream) : gs.sorted.alloc((size_t)sorted_total + 4));
         GPSCAL_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(unsigned) * ((size_t)cells + 1), ctx->stream));
         if (npairs > 0 && W.mmax > 0) {
             int maxlev = 1;

@@ -157,14 +157,14 @@ def _rccl_world_of_one_body(ctx, monkeypatch):
     cnts = np.array([16 * npairs], dtype=np.int32)
     sb.icp(50, want_err=False, T_out=d_T)  # warm-up: graph capture
     ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(16):  # ~20 ms of queued work (16 graph replays of 24 x 50 iterations) behind ~2 ms of host calls ...
+    for _ in range(16):  # 16 graph replays of 24 x 50 iterations queued: milliseconds of work still pending ...
         sb.icp(50, want_err=False, T_out=d_T)  # (no set_pose here: a host pose makes that call wait for the stream)
+    t1 = time.perf_counter()
     ctx._ck(ctx._L.gpscal_allgather_chains(ctx._h, _ptr(d_T), _ptr(cnts), _ptr(d_all)), "allgather behind work")
-    t_call = time.perf_counter() - t0
+    t_call = time.perf_counter() - t1
     ctx.sync()
-    t_all = time.perf_counter() - t0
-    assert t_call < 0.6 * t_all, (t_call, t_all)  # ... which the gather did not wait for
+    t_drain = time.perf_counter() - t1
+    assert t_call < 0.25 * t_drain, (t_call, t_drain)  # ... which the gather did not wait for
     torch.cuda.synchronize()
     assert torch.equal(d_T, d_all)
     sb.close()
