@@ -492,7 +492,7 @@ __device__ __forceinline__ void wave_reduce_terms(const double *t, double *__res
 // synchronises the workgroup and adds them).  T: the pair's float32 pose (12 values).  Shared by icp_step_kernel
 // (one launch per iteration) and icp_persistent_kernel (all iterations of small batches in one launch).
 struct StepArgs {
-    const float4 *__restrict__ src4;
+    const float *__restrict__ src3;  // grouped source points, 12 bytes each
     const double *__restrict__ wsrc;
     const float4 *__restrict__ sorted;
     const float4 *__restrict__ nbr;
@@ -500,8 +500,8 @@ struct StepArgs {
     const unsigned *__restrict__ cell_start;
     int *__restrict__ nn_idx;
     float *__restrict__ nn_sqd;
-    float4 *__restrict__ warm_q;
-    unsigned *__restrict__ warm_r2;
+    float4 *__restrict__ warm_q;  // last iteration's neighbour: x, y, z and its two certified radii in one word
+    int *__restrict__ warm_i;     // ... and its index (read only by queries the first certificate does not settle)
 };
 template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK>
 __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc &P, const float *T, int first, int src_n,
@@ -509,7 +509,7 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
                                           double (&wsum)[STEP_BLOCK / 64][WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN],
                                           double (&tslab)[STEP_BLOCK / 64][8][64])
 {
-    const float4 *__restrict__ src4 = A.src4;
+    const float *__restrict__ src3 = A.src3;
     const double *__restrict__ wsrc = A.wsrc;
     const float4 *__restrict__ sorted = A.sorted;
     const float4 *__restrict__ nbr = A.nbr;
@@ -518,7 +518,7 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
     int *__restrict__ nn_idx = A.nn_idx;
     float *__restrict__ nn_sqd = A.nn_sqd;
     float4 *__restrict__ warm_q = A.warm_q;
-    unsigned *__restrict__ warm_r2 = A.warm_r2;
+    int *__restrict__ warm_i = A.warm_i;
     const float r00 = T[0], r01 = T[1], r02 = T[2], tx = T[3];
     const float r10 = T[4], r11 = T[5], r12 = T[6], ty = T[7];
     const float r20 = T[8], r21 = T[9], r22 = T[10], tz = T[11];
@@ -537,33 +537,38 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
     for (int q = 0; q < QPT; ++q) {
         const int i = first + q * STEP_BLOCK + (int)threadIdx.x;
         const bool valid = i < src_n;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 wq = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
-        float2 wr2 = make_float2(0.f, 0.f);
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) {
-            // three coalesced streams: the point, last iteration's neighbour, its radii
-            s = src4[src_off + i];
+            // two coalesced streams, 28 bytes per query: the point, and last iteration's neighbour with its radii
+            const float *sp = src3 + 3 * (src_off + i);
+            sx = sp[0]; sy = sp[1]; sz = sp[2];
             wq = warm_q[src_off + i];
-            // both radii in one word: the upper 16 bits of each float (truncation only shrinks a radius,
-            // which keeps the certificates valid)
-            const unsigned pr = warm_r2[src_off + i];
-            wr2 = make_float2(__uint_as_float(pr & 0xffff0000u), __uint_as_float(pr << 16));
         }
-        bool ok = valid && finite3(s.x, s.y, s.z);
-        const float px = __fmaf_rn(r00, s.x, __fmaf_rn(r01, s.y, __fmaf_rn(r02, s.z, tx)));
-        const float py = __fmaf_rn(r10, s.x, __fmaf_rn(r11, s.y, __fmaf_rn(r12, s.z, ty)));
-        const float pz = __fmaf_rn(r20, s.x, __fmaf_rn(r21, s.y, __fmaf_rn(r22, s.z, tz)));
+        // both radii in one word: the upper 16 bits of each float (truncation only shrinks a radius, which keeps the
+        // certificates valid); a zero word = no remembered neighbour
+        const unsigned pr = __float_as_uint(wq.w);
+        const float ra2 = __uint_as_float(pr & 0xffff0000u), rb2 = __uint_as_float(pr << 16);
+        bool ok = valid && finite3(sx, sy, sz);
+        const float px = __fmaf_rn(r00, sx, __fmaf_rn(r01, sy, __fmaf_rn(r02, sz, tx)));
+        const float py = __fmaf_rn(r10, sx, __fmaf_rn(r11, sy, __fmaf_rn(r12, sz, ty)));
+        const float pz = __fmaf_rn(r20, sx, __fmaf_rn(r21, sy, __fmaf_rn(r22, sz, tz)));
+        const bool warm = ok && pr != 0u;
+        const float d0 = sqdist(px, py, pz, wq.x, wq.y, wq.z);
+        const bool t1 = warm && d0 < ra2;  // tier 1: inside r_a, the remembered neighbour is proven nearest
+        bool need = ok && !t1;             // still needs the grid search
+        // the neighbour's index: a third stream only for the queries tier 1 leaves (and for everybody in the launch that
+        // writes the correspondences out)
+        int wi = 0x7fffffff;
+        if (warm && (!t1 || (write_nn & 1))) wi = warm_i[src_off + i];
+        float4 nq = make_float4(wq.x, wq.y, wq.z, __int_as_float(wi));  // the neighbour this iteration ends with
         BestQ B;
         B.init();
-        bool need = ok;  // still needs the grid search
-        float4 nq = wq;  // the neighbour this iteration ends with
-        if (ok && __float_as_int(wq.w) != 0x7fffffff) {
-            const float d0 = sqdist(px, py, pz, wq.x, wq.y, wq.z);
-            B.consider(d0, wq, BestQ::WARM);
-            need = !(d0 < wr2.x);  // tier 1: inside r_a, proven nearest
-            if (need && d0 < wr2.y && !(diag & 4)) {
+        if (warm) {
+            B.consider(d0, nq, BestQ::WARM);
+            if (need && d0 < rb2 && !(diag & 4)) {
                 // tier 2: inside r_b the answer is q0 or one of its 4 listed neighbours
-                const float4 *nb = nbr + 4 * (tgt_off + __float_as_int(wq.w));
+                const float4 *nb = nbr + 4 * (tgt_off + wi);
                 const float4 n0 = nb[0], n1 = nb[1], n2 = nb[2], n3 = nb[3];
                 B.consider(sqdist(px, py, pz, n0.x, n0.y, n0.z), n0, BestQ::LIST + 0);
                 B.consider(sqdist(px, py, pz, n1.x, n1.y, n1.z), n1, BestQ::LIST + 1);
@@ -582,14 +587,14 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
 #endif
         if (__ballot(need) != 0ull)  // wave-uniform: a settled wave skips the search's set-up as well
             knn_query<BestQ, BALL>(P, sorted, cell_start, need, px, py, pz, B, diag >> 8);
-        ok = ok && B.index() != 0x7fffffff;
+        ok = ok && (t1 || B.index() != 0x7fffffff);  // (a query tier 1 settles may not have read its neighbour's index)
         if (ok && B.pos != BestQ::WARM) {
             // the neighbour changed: remember it and its radii for the next iteration
-            nq = B.pos < BestQ::LIST ? sorted[B.pos]
-                                     : nbr[4 * (tgt_off + __float_as_int(wq.w)) + (B.pos - BestQ::LIST)];
-            warm_q[src_off + i] = nq;
+            nq = B.pos < BestQ::LIST ? sorted[B.pos] : nbr[4 * (tgt_off + wi) + (B.pos - BestQ::LIST)];
             const float2 r2 = pt_r2[tgt_off + B.index()];
-            warm_r2[src_off + i] = (__float_as_uint(r2.x) & 0xffff0000u) | (__float_as_uint(r2.y) >> 16);
+            const unsigned npr = (__float_as_uint(r2.x) & 0xffff0000u) | (__float_as_uint(r2.y) >> 16);
+            warm_q[src_off + i] = make_float4(nq.x, nq.y, nq.z, __uint_as_float(npr));
+            warm_i[src_off + i] = __float_as_int(nq.w);
         }
         const float bd = B.dist2();
         if (valid && (write_nn & 1)) {  // the correspondences are an output of the run's last iteration only
@@ -609,10 +614,10 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
 template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK>
 __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
     const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
-    const float4 *__restrict__ src4, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
+    const float *__restrict__ src3, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
     const float4 *__restrict__ nbr, const float2 *__restrict__ pt_r2, const unsigned *__restrict__ cell_start,
     const float *__restrict__ pose32, int *__restrict__ nn_idx, float *__restrict__ nn_sqd,
-    float4 *__restrict__ warm_q, unsigned *__restrict__ warm_r2, double *__restrict__ partials, int nblk, int diag,
+    float4 *__restrict__ warm_q, int *__restrict__ warm_i, double *__restrict__ partials, int nblk, int diag,
     int write_nn, int uni_n, int uni_m, int uni_bpp, int uni_pair0)
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
         src_off = pairs[b].src_off;
         tgt_off = pairs[b].tgt_off;
     }
-    const StepArgs A = {src4, wsrc, sorted, nbr, pt_r2, cell_start, nn_idx, nn_sqd, warm_q, warm_r2};
+    const StepArgs A = {src3, wsrc, sorted, nbr, pt_r2, cell_start, nn_idx, nn_sqd, warm_q, warm_i};
     step_body<QPT, WEIGHTED, BALL, STEP_BLOCK>(A, pairs[b], pose32 + (size_t)b * 12, first, src_n, src_off, tgt_off, diag,
                                                write_nn, wsum, tslab);
     __syncthreads();
@@ -850,12 +855,25 @@ __global__ __launch_bounds__(PERSIST_BLOCK) void icp_persistent_kernel(
     }
 }
 
-__global__ void fill_warm_kernel(float4 *__restrict__ warm_q, unsigned *__restrict__ warm_r2, long long n)
+__global__ void fill_warm_kernel(float4 *__restrict__ warm_q, int *__restrict__ warm_i, long long n)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    warm_q[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));  // index INT_MAX = no warm start
-    warm_r2[i] = 0u;
+    warm_q[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // radii word 0 = no warm start
+    warm_i[i] = 0x7fffffff;
+}
+
+// The grouped source as the step kernel reads it: 12 bytes per point, the original indices aside.
+__global__ void split_source_kernel(const float4 *__restrict__ src4, float *__restrict__ src3, int *__restrict__ src_orig,
+                                    long long n)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = src4[i];
+    src3[3 * i] = p.x;
+    src3[3 * i + 1] = p.y;
+    src3[3 * i + 2] = p.z;
+    src_orig[i] = __float_as_int(p.w);
 }
 
 __global__ void pose_to_f32_kernel(const double *__restrict__ pose64, float *__restrict__ pose32, int npairs)
@@ -866,26 +884,26 @@ __global__ void pose_to_f32_kernel(const double *__restrict__ pose64, float *__r
     pose32[i] = (float)pose64[(size_t)b * 16 + k];
 }
 
-__global__ void unsort_nn_kernel(const PairDesc *__restrict__ pairs, const float4 *__restrict__ src4,
+__global__ void unsort_nn_kernel(const PairDesc *__restrict__ pairs, const int *__restrict__ src_orig,
                                  const int *__restrict__ nn_idx, const float *__restrict__ nn_sqd,
                                  int *__restrict__ idx_out, float *__restrict__ sqd_out)
 {
     int b = blockIdx.y;
     const PairDesc &P = pairs[b];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += gridDim.x * blockDim.x) {
-        int orig = __float_as_int(src4[P.src_off + i].w);
+        int orig = src_orig[P.src_off + i];
         idx_out[P.src_off + orig] = nn_idx[P.src_off + i];
         sqd_out[P.src_off + orig] = nn_sqd[P.src_off + i];
     }
 }
 
-__global__ void gather_weights_kernel(const PairDesc *__restrict__ pairs, const float4 *__restrict__ src4,
+__global__ void gather_weights_kernel(const PairDesc *__restrict__ pairs, const int *__restrict__ src_orig,
                                       const double *__restrict__ w_in, double *__restrict__ w_sorted)
 {
     int b = blockIdx.y;
     const PairDesc &P = pairs[b];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += gridDim.x * blockDim.x) {
-        int orig = __float_as_int(src4[P.src_off + i].w);
+        int orig = src_orig[P.src_off + i];
         w_sorted[P.src_off + i] = w_in[P.src_off + orig];
     }
 }
@@ -1251,13 +1269,15 @@ struct gpscal_scan_batch {
     int ball_r = 0;  // block radius of the ball search (0 = fine -> coarse 3x3x3 search)
     DevBuf<PairDesc> pairs;  // target descs + source fields
     std::vector<PairDesc> hpairs;
-    DevBuf<float4> src4;
+    DevBuf<float4> src4;  // the grouped source as the grouping leaves it (released once split)
+    DevBuf<float> src3;   // ... as the step kernel reads it: xyz, 12 bytes per point
+    DevBuf<int> src_orig;  // ... and every grouped point's original index
     DevBuf<double> wsorted;
     DevBuf<int> blk_pair, blk_first;
     DevBuf<int> nn_idx;
     DevBuf<float> nn_sqd;
-    DevBuf<float4> warm_q;  // warm start: last iteration's neighbour (xyz + index bits) per source point
-    DevBuf<unsigned> warm_r2;  // ... and its certified radii (r_a^2, r_b^2), 16 bits each (truncated floats)
+    DevBuf<float4> warm_q;  // warm start: last iteration's neighbour (xyz + radii word) per source point
+    DevBuf<int> warm_i;  // ... its index; warm_q.w holds the certified radii (r_a^2, r_b^2), 16 bits each (truncated floats)
     DevBuf<double> partials, pose64, err_hist;
     DevBuf<float> pose32;
     int err_cap = 0;
@@ -1395,6 +1415,13 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
     std::swap(B->src4.n, sg.sorted.n);
     std::swap(B->src4.pooled, sg.sorted.pooled);
     std::swap(B->src4.pool_stream, sg.sorted.pool_stream);
+    // ... and is split into what the iterations read (12 bytes per point) and the original indices
+    GPSCAL_HIP(ctx, B->src3.alloc_async((size_t)std::max<long long>(3 * B->total_n, 1), ctx->stream));
+    GPSCAL_HIP(ctx, B->src_orig.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
+    if (B->total_n > 0)
+        hipLaunchKernelGGL(split_source_kernel, dim3(div_up(B->total_n, BLOCK)), dim3(BLOCK), 0, ctx->stream, B->src4.p,
+                           B->src3.p, B->src_orig.p, B->total_n);
+    B->src4.release();
     // block table
     const long long per_blk_target = (long long)ctx->prop.multiProcessorCount * 8 * BLOCK;
     (void)per_blk_target;
@@ -1490,16 +1517,16 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
         GPSCAL_HIP(ctx, win.bind(ctx, w, (size_t)B->total_n));
         GPSCAL_HIP(ctx, B->wsorted.alloc_async((size_t)B->total_n, ctx->stream));
         int gx = std::max(1, std::min(div_up(maxn, BLOCK), 1024));
-        hipLaunchKernelGGL(gather_weights_kernel, dim3(gx, np), dim3(BLOCK), 0, ctx->stream, B->pairs.p, B->src4.p,
+        hipLaunchKernelGGL(gather_weights_kernel, dim3(gx, np), dim3(BLOCK), 0, ctx->stream, B->pairs.p, B->src_orig.p,
                            win.dev, B->wsorted.p);
         GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     GPSCAL_HIP(ctx, B->nn_idx.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
     GPSCAL_HIP(ctx, B->nn_sqd.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
     GPSCAL_HIP(ctx, B->warm_q.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
-    GPSCAL_HIP(ctx, B->warm_r2.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
+    GPSCAL_HIP(ctx, B->warm_i.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
     hipLaunchKernelGGL(fill_warm_kernel, dim3(div_up(std::max<long long>(B->total_n, 1), BLOCK)), dim3(BLOCK), 0,
-                       ctx->stream, B->warm_q.p, B->warm_r2.p, B->total_n);
+                       ctx->stream, B->warm_q.p, B->warm_i.p, B->total_n);
     GPSCAL_HIP(ctx, B->partials.alloc_async((size_t)std::max(B->nblk, 1) * NACC_WEIGHTED, ctx->stream));
     if (B->persistent) GPSCAL_HIP(ctx, B->ctl.alloc_async((size_t)np, ctx->stream));
     GPSCAL_HIP(ctx, B->pose64.alloc_async((size_t)np * 16, ctx->stream));
@@ -1568,7 +1595,7 @@ extern "C" int gpscal_scan_batch_set_pose(gpscal_scan_batch *B, const double *T0
     // a new pose starts a new problem: the neighbours remembered from the previous run are forgotten, so
     // that a run never profits from correspondences an earlier run computed
     hipLaunchKernelGGL(fill_warm_kernel, dim3(div_up(std::max<long long>(B->total_n, 1), BLOCK)), dim3(BLOCK), 0,
-                       ctx->stream, B->warm_q.p, B->warm_r2.p, B->total_n);
+                       ctx->stream, B->warm_q.p, B->warm_i.p, B->total_n);
     GPSCAL_HIP(ctx, hipGetLastError());
     return GPSCAL_OK;
 }
@@ -1604,8 +1631,8 @@ static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st, 
     } while (0)
 #define STEP_BS(QPT, W, BALL, BS)                                                                                        \
     hipLaunchKernelGGL((icp_step_kernel<QPT, W, BALL, BS>), dim3(nb), dim3(BS), 0, st, B->pairs.p, B->blk_pair.p + b0, \
-                       B->blk_first.p + b0, B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p, G.cell_start,   \
-                       B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p,                              \
+                       B->blk_first.p + b0, B->src3.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p, G.cell_start,   \
+                       B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_i.p,                               \
                        B->partials.p + (size_t)b0 * (B->weighted ? NACC_WEIGHTED : NACC_PLAIN), nb,                  \
                        (B->diag & 0xff) | (B->ball_r << 8), (last ? 1 : 0) | (want_err ? 0 : 2), B->uni_n, B->uni_m,   \
                        B->uni_bpp, c < 0 ? 0 : B->chain_pair[c])
@@ -1667,8 +1694,8 @@ extern "C" int gpscal_scan_batch_icp(gpscal_scan_batch *B, int iters, double *T_
         GPSCAL_HIP(ctx, hipMemsetAsync(B->ctl.p, 0, sizeof(IcpCtl) * np, ctx->stream));
         if (want_err)  // (a pair without source points has no workgroup: its history reads zero, as the solve kernel leaves it)
             GPSCAL_HIP(ctx, hipMemsetAsync(B->err_hist.p, 0, sizeof(double) * (size_t)np * B->err_cap, ctx->stream));
-        const StepArgs A = {B->src4.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p, G.cell_start,
-                            B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_r2.p};
+        const StepArgs A = {B->src3.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p, G.cell_start,
+                            B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_i.p};
 #define PERSIST(W, BALL)                                                                                            \
     hipLaunchKernelGGL((icp_persistent_kernel<W, BALL>), dim3(B->nblk), dim3(PERSIST_BLOCK), 0, ctx->stream,         \
                        B->pairs.p, B->blk_pair.p, B->blk_first.p, A, B->partials.p, B->pose64.p, B->pose32.p,        \
@@ -1763,7 +1790,7 @@ extern "C" int gpscal_scan_batch_correspondences(gpscal_scan_batch *B, int32_t *
     long long maxn = 0;
     for (auto &P : B->hpairs) maxn = std::max<long long>(maxn, P.n);
     int gx = std::max(1, std::min(div_up(maxn, BLOCK), 1024));
-    hipLaunchKernelGGL(unsort_nn_kernel, dim3(gx, B->npairs), dim3(BLOCK), 0, ctx->stream, B->pairs.p, B->src4.p,
+    hipLaunchKernelGGL(unsort_nn_kernel, dim3(gx, B->npairs), dim3(BLOCK), 0, ctx->stream, B->pairs.p, B->src_orig.p,
                        B->nn_idx.p, B->nn_sqd.p, oi.dev, od.dev);
     GPSCAL_HIP(ctx, hipGetLastError());
     bool sync = false;
