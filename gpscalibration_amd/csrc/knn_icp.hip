@@ -462,27 +462,30 @@ __device__ __forceinline__ double dpp_shr_add_f64(double v)
 }
 
 // Sum of every term over the 64 lanes, in fixed order: 8 terms at a time are transposed through the wave's slab
-// (lane (k, seg) adds 8 consecutive lanes' copies of term k, three DPP steps fold the 8 segments); lane 8k+7 ends up
-// with term g0+k and hands it to `sink(term, value)`.  ~20 vector instructions per 8 terms against ~160 for 8 full
-// DPP wave reductions.
+// (lane (k, c) adds the copies of term k of lanes c, c + 8, ... c + 56, three DPP steps fold the 8 columns); lane 8k+7
+// ends up with term g0+k and hands it to `sink(term, value)`.  ~20 vector instructions per 8 terms against ~160 for
+// 8 full DPP wave reductions.  The LDS traffic of this transpose (16 KB per wave) is what bounds a converged launch,
+// so it is laid out free of bank conflicts: rows of 72 doubles (a row starts 16 banks behind the previous one) and
+// column-wise 8-byte reads -- 32 lanes of a read touch 4 rows x 16 banks = every bank once -- where row-wise 16-byte
+// reads of 512-byte rows hit four banks sixteen times.
+constexpr int SLAB_PITCH = 72;
 template <int NT, class Sink>
 __device__ __forceinline__ void wave_reduce_terms(const double *t, double *__restrict__ slab, Sink sink)
 {
     const int lane = threadIdx.x & 63;
-    const int k = lane >> 3, seg = lane & 7;
-    const double2 *row = reinterpret_cast<const double2 *>(slab + k * 64 + seg * 8);
+    const int k = lane >> 3, c = lane & 7;
+    const double *col = slab + k * SLAB_PITCH + c;
 #pragma unroll
     for (int g0 = 0; g0 < NT; g0 += 8) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (g0 + j < NT) slab[j * 64 + lane] = t[g0 + j];
+            if (g0 + j < NT) slab[j * SLAB_PITCH + lane] = t[g0 + j];
         __builtin_amdgcn_wave_barrier();
-        const double2 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
-        double v = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
+        double v = ((col[0] + col[8]) + (col[16] + col[24])) + ((col[32] + col[40]) + (col[48] + col[56]));
         v = dpp_shr_add_f64<0x111>(v);  // row_shr:1
         v = dpp_shr_add_f64<0x112>(v);  // row_shr:2
         v = dpp_shr_add_f64<0x114>(v);  // row_shr:4 -> lane 8k+7 holds term k
-        if (seg == 7 && g0 + k < NT) sink(g0 + k, v);
+        if (c == 7 && g0 + k < NT) sink(g0 + k, v);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -507,7 +510,7 @@ template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK>
 __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc &P, const float *T, int first, int src_n,
                                           long long src_off, long long tgt_off, int diag, int write_nn,
                                           double (&wsum)[STEP_BLOCK / 64][WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN],
-                                          double (&tslab)[STEP_BLOCK / 64][8][64])
+                                          double (&tslab)[STEP_BLOCK / 64][8][SLAB_PITCH])
 {
     const float *__restrict__ src3 = A.src3;
     const double *__restrict__ wsrc = A.wsrc;
@@ -611,8 +614,11 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
     return n_need;
 }
 
+#ifndef GPSCAL_STEP_MINW
+#define GPSCAL_STEP_MINW 1
+#endif
 template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK>
-__global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
+__global__ __launch_bounds__(STEP_BLOCK, GPSCAL_STEP_MINW) void icp_step_kernel(
     const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
     const float *__restrict__ src3, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
     const float4 *__restrict__ nbr, const float2 *__restrict__ pt_r2, const unsigned *__restrict__ cell_start,
@@ -622,7 +628,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void icp_step_kernel(
 {
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
     __shared__ double wsum[STEP_BLOCK / 64][NACC];
-    __shared__ double tslab[STEP_BLOCK / 64][8][64];  // per-wave transpose slab (4 KiB / wave)
+    __shared__ double tslab[STEP_BLOCK / 64][8][SLAB_PITCH];  // per-wave transpose slab (4.5 KiB / wave)
 
     const int lb = xcd_remap(blockIdx.x, nblk);
     // A batch of equal-sized scans (uni_n > 0: every source cloud uni_n points, every target cloud uni_m, stored back
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(PERSIST_BLOCK) void icp_persistent_kernel(
     constexpr int NACC = WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN;
     constexpr int NW = PERSIST_BLOCK / 64;
     __shared__ double wsum[NW][NACC];
-    __shared__ double tslab[NW][8][64];
+    __shared__ double tslab[NW][8][SLAB_PITCH];
     __shared__ float s_pose[12];
     __shared__ int s_flag;
 
