@@ -1240,9 +1240,8 @@ int ensure_safe_radius(gpscal_ctx *ctx, GridSet &gs)
     const size_t slots = (size_t)std::max<long long>(total, 1);
     GPSCAL_HIP(ctx, gs.pooled ? gs.nbr.alloc_async(slots * 4, ctx->stream) : gs.nbr.alloc(slots * 4));
     GPSCAL_HIP(ctx, gs.pooled ? gs.pt_r2.alloc_async(slots, ctx->stream) : gs.pt_r2.alloc(slots));
-    // non-finite points are never indexed nor returned: their slots stay zero
-    GPSCAL_HIP(ctx, hipMemsetAsync(gs.nbr.p, 0, sizeof(float4) * 4 * (size_t)std::max<long long>(total, 1), ctx->stream));
-    GPSCAL_HIP(ctx, hipMemsetAsync(gs.pt_r2.p, 0, sizeof(float2) * (size_t)std::max<long long>(total, 1), ctx->stream));
+    // (non-finite points are never indexed nor returned, so nobody reads their slots: no clearing pass -- it was 50 us
+    // of a 64 x 65 536 build for 300 MB that the kernel below overwrites)
     int mmax = 0;
     for (auto &P : gs.hpairs) mmax = std::max(mmax, P.m);
     if (mmax > 0) {
@@ -1251,7 +1250,8 @@ int ensure_safe_radius(gpscal_ctx *ctx, GridSet &gs)
                            gs.cell_start, gs.pts4.p, gs.nbr.p, gs.pt_r2.p);
     }
     GPSCAL_HIP(ctx, hipGetLastError());
-    GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // a set with plain allocations may be used from another stream next; a pooled one lives on this stream
+    if (!gs.pooled) GPSCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GPSCAL_OK;
 }
 
@@ -1391,7 +1391,9 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
     // spatially group each source cloud by its own level-0 cells
     GridSet sg;
     sg.pooled = true;  // per-call: blocks of the stream's cache (src4 below takes one of them over)
-    int rc = build_grids(ctx, src_xyz, stride, src_off, np, 0.f, 1, sg);
+    float src_cell = 0.f;  // (0: three points per cell of the footprint; GPSCAL_SRC_CELL=-12: twelve)
+    if (const char *e = getenv("GPSCAL_SRC_CELL")) src_cell = (float)atof(e);
+    int rc = build_grids(ctx, src_xyz, stride, src_off, np, src_cell, 1, sg);
     if (rc) return rc;
     B->total_n = sg.total_sorted;
     // steal the grouped array: with one level `sorted` is exactly src4, except
@@ -1531,8 +1533,7 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
     GPSCAL_HIP(ctx, B->nn_sqd.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
     GPSCAL_HIP(ctx, B->warm_q.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
     GPSCAL_HIP(ctx, B->warm_i.alloc_async((size_t)std::max<long long>(B->total_n, 1), ctx->stream));
-    hipLaunchKernelGGL(fill_warm_kernel, dim3(div_up(std::max<long long>(B->total_n, 1), BLOCK)), dim3(BLOCK), 0,
-                       ctx->stream, B->warm_q.p, B->warm_i.p, B->total_n);
+    // (filled by gpscal_scan_batch_set_pose, which gpscal_scan_batch_create calls last)
     GPSCAL_HIP(ctx, B->partials.alloc_async((size_t)std::max(B->nblk, 1) * NACC_WEIGHTED, ctx->stream));
     if (B->persistent) GPSCAL_HIP(ctx, B->ctl.alloc_async((size_t)np, ctx->stream));
     GPSCAL_HIP(ctx, B->pose64.alloc_async((size_t)np * 16, ctx->stream));
