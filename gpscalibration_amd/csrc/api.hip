@@ -64,7 +64,11 @@ extern "C" int gpscal_destroy(gpscal_ctx *ctx)
     if (ctx->comm) (void)gpscal_comm_destroy(ctx);
     if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     for (int k = 0; k < gpscal_ctx::MAX_SIDE; ++k) {
-        if (ctx->side_stream[k]) (void)hipStreamDestroy(ctx->side_stream[k]);
+        if (ctx->side_stream[k]) {
+            (void)hipStreamSynchronize(ctx->side_stream[k]);
+            cache_retire(ctx->side_stream[k]);  // (a build's source grouping leaves cached blocks here)
+            (void)hipStreamDestroy(ctx->side_stream[k]);
+        }
         if (ctx->side_event[k]) (void)hipEventDestroy(ctx->side_event[k]);
     }
     if (ctx->worker_stream) {

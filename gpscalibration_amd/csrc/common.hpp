@@ -175,6 +175,24 @@ inline void cache_retire(hipStream_t stream)
     }
     cache_retired().insert(stream);
 }
+// The context's k-th side stream and event, created on first use (the chains of a scan batch's graph, the two side
+// chains of its build).  A side stream may own cached blocks (the source grouping of a build runs on one), so it is
+// registered with the block cache like the context's own stream and retired in gpscal_destroy.
+inline hipError_t side_stream_of(gpscal_ctx *ctx, int k, hipStream_t *st, hipEvent_t *ev)
+{
+    if (!ctx->side_stream[k]) {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->side_stream[k], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        cache_revive(ctx->side_stream[k]);
+    }
+    if (!ctx->side_event[k]) {
+        hipError_t e = hipEventCreateWithFlags(&ctx->side_event[k], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    if (st) *st = ctx->side_stream[k];
+    if (ev) *ev = ctx->side_event[k];
+    return hipSuccess;
+}
 // Out of memory: what idles in ANY stream's cache is given back (up to an eighth of the device per stream may sit there).
 inline void cache_trim_all()
 {

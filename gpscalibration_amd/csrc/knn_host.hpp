@@ -38,7 +38,9 @@ struct GridSource {
 };
 int build_grids_multi(gpscal_ctx *ctx, int nsrc, const GridSource *src, int stride, float cell, int max_levels);
 // Neighbour lists + certified radii (ICP only).
-int ensure_safe_radius(gpscal_ctx *ctx, GridSet &gs);
+// `side` + `done`: the kernel runs on that stream behind what ctx->stream holds now, `done` is recorded behind it and
+// the CALLER makes its stream wait for it (gpscal_scan_batch_create: the source grouping runs beside the kernel).
+int ensure_safe_radius(gpscal_ctx *ctx, GridSet &gs, hipStream_t side = nullptr, hipEvent_t done = nullptr);
 
 }  // namespace gpscal
 
