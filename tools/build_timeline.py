@@ -1,9 +1,12 @@
-"""Kernel timeline of the last index build in a rocprofv3 kernel trace of tools/build_run.py: python tools/build_timeline.py <dir>"""
+"""Kernel timeline of the last index build in a rocprofv3 kernel trace of tools/build_probe.py (start, gap to the
+previous kernel's end -- negative where two streams overlap --, duration): python tools/build_timeline.py <trace dir or *_kernel_trace.csv>"""
 import csv
 import glob
 import sys
 rows = []
-for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+import os
+files = [sys.argv[1]] if os.path.isfile(sys.argv[1]) else glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)
+for f in files:
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("gpscal::", "")[:44]))
 rows.sort()

@@ -11,7 +11,7 @@ echo "{}" > $O/pmc_traffic.json
 for cfg in "64 65536 50 4194304" "125 262144 20 32768000" "32 1048576 50 33554432"; do
   set -- $cfg
   bash $R/tools/icp_traffic_iter.sh $O/pmc_$1x$2 $3 $1 $2 || exit 1
-  python tools/pmc_traffic_report.py $O/pmc_$1x$2 $4 pairs$1_points$2 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/icp_iter_run.py $3 $1 $2 (second run, learnt schedule), round 3" $3 > $O/one.json || exit 1
+  python tools/pmc_traffic_report.py $O/pmc_$1x$2 $4 pairs$1_points$2 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/icp_iter_run.py $3 $1 $2 (second run of the batch), round 3" $3 > $O/one.json || exit 1
   python - $O/pmc_traffic.json $O/one.json <<'PY'
 import json, sys
 a = json.load(open(sys.argv[1])); a.update(json.load(open(sys.argv[2]))); json.dump(a, open(sys.argv[1], "w"), indent=1)
