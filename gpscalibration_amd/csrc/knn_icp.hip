@@ -14,9 +14,13 @@
 //                                        the 3 x-neighbours of a row are ONE run)
 //   cell_start  uint32[total cells + 1]  global exclusive scan of the cell counts
 //                                        = absolute position of each cell in `sorted`
-//   src4        float4[sum n]            sources grouped by their own level-0 cell
-//                                        (rigid motion keeps that order coherent)
-//   nn_idx/sqd  int32/float[sum n]       correspondences, in src4 order
+//   src3        float[sum n][3]          sources grouped by their own level-0 cell
+//                                        (rigid motion keeps that order coherent);
+//                                        src_orig int32[sum n]: their original indices
+//   warm_q      float4[sum n]            last iteration's neighbour of every source point:
+//                                        xyz + its two certified radii in one word;
+//                                        warm_i int32[sum n]: its index
+//   nn_idx/sqd  int32/float[sum n]       correspondences, in grouped order
 //   partials    double[blocks][NACC]     per-block sums, reduced in fixed order
 //   pose        double[pairs][16] + float[pairs][12]
 // Roofline: HBM; algorithmic bytes per iteration = 20 n + 12 m.

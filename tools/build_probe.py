@@ -1,5 +1,6 @@
-import sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from gpscalibration_amd import Context, synth
 npairs, n = int(sys.argv[1]), int(sys.argv[2])
