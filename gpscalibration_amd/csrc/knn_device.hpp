@@ -175,6 +175,52 @@ struct Best {
     }
 };
 
+// The k best as K ascending 64-bit keys (d2 bits << 32 | index: d2 >= 0, so a key orders like (d2, index)), updated by
+// a branch-free insertion network: c_k = x < key_k for every k, then key_k <- c_k ? (c_{k-1} ? key_{k-1} : x) : key_k --
+// K compares and ~4 K selects, no masked block, no bubble loop.  With 64 queries in a wave some lane accepts nearly
+// every candidate, so the wave pays the insertion per candidate STEP; Best<K>'s guarded bubble insert is ~45 vector +
+// ~15 scalar instructions there (self_nn_kernel, K = 6: 6 020 + 3 560 per wave by the SQ counters), this one 34 + 10.
+// Same acceptance rule, order and duplicate rule as Best<K> (a coarser level re-visits the points of the finer ones:
+// a key that is already in the list is not inserted again), hence the same results.
+template <int K>
+struct BestKeys {
+    static constexpr bool COOP = false;
+    static constexpr bool WARM_START = true;
+    static constexpr bool BALL = false;
+    unsigned long long key[K];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) key[k] = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, INT_MAX)
+    }
+    __device__ __forceinline__ void init_radius(float r2)
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) key[k] = ((unsigned long long)__float_as_uint(r2) << 32) | 0x7fffffffu;
+    }
+    __device__ __forceinline__ float dist2(int k) const { return __uint_as_float((unsigned)(key[k] >> 32)); }
+    __device__ __forceinline__ int index(int k) const { return (int)(unsigned)key[k]; }
+    __device__ __forceinline__ float worst() const { return dist2(K - 1); }
+    __device__ __forceinline__ bool seeded() const { return index(K - 1) != 0x7fffffff; }
+    __device__ __forceinline__ void consider(float d2, const float4 &c, unsigned)
+    {
+        const unsigned long long x = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(c.w);
+        bool lt[K];
+        bool dup = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            lt[k] = x < key[k];
+            if (K > 1) dup |= x == key[k];
+        }
+#pragma unroll
+        for (int k = K - 1; k > 0; --k) {
+            const unsigned long long in = lt[k - 1] ? key[k - 1] : x;
+            key[k] = (lt[k] && !dup) ? in : key[k];
+        }
+        key[0] = (lt[0] && !dup) ? x : key[0];
+    }
+};
+
 // 1-NN record of the ICP kernel.  (d2, index) live in one 64-bit key -- d2 >= 0, so
 // its float bits order like the value and the key orders exactly like (d2, index):
 // accepting a candidate is one v_cmp_lt_u64 and three v_cndmask.  `pos` is the

@@ -283,15 +283,15 @@ __global__ __launch_bounds__(BLOCK) void knn_search_kernel(const PairDesc *__res
         const float *q = reinterpret_cast<const float *>(qraw + (size_t)i * stride);
         px = q[0]; py = q[1]; pz = q[2];
     }
-    Best<K> B;
+    BestKeys<K> B;
     B.init();
     knn_query(P, sorted, cell_start, i < n && finite3(px, py, pz), px, py, pz, B);
     if (i >= n) return;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        bool ok = B.i[k] != 0x7fffffff;
-        idx[(size_t)i * K + k] = ok ? B.i[k] : -1;
-        sqd[(size_t)i * K + k] = ok ? B.d[k] : INFINITY;
+        bool ok = B.index(k) != 0x7fffffff;
+        idx[(size_t)i * K + k] = ok ? B.index(k) : -1;
+        sqd[(size_t)i * K + k] = ok ? B.dist2(k) : INFINITY;
     }
 }
 
@@ -307,7 +307,10 @@ __global__ __launch_bounds__(BLOCK) void knn_search_kernel(const PairDesc *__res
 #ifndef GPSCAL_SELF_NN_FLAT
 #define GPSCAL_SELF_NN_FLAT 1
 #endif
-__global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restrict__ pairs,
+#ifndef GPSCAL_SELFNN_MINW
+#define GPSCAL_SELFNN_MINW 1
+#endif
+__global__ __launch_bounds__(BLOCK, GPSCAL_SELFNN_MINW) void self_nn_kernel(const PairDesc *__restrict__ pairs,
                                                          const float4 *__restrict__ sorted,
                                                          const unsigned *__restrict__ cell_start,
                                                          const float4 *__restrict__ pts4, float4 *__restrict__ nbr,
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
         const bool act = j < end0;
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
         if (act) c = sorted[j];
-        Best<6> B;
+        BestKeys<6> B;
         B.init();
         knn_query(P, sorted, cell_start, act, c.x, c.y, c.z, B, 0, slab);
         if (!act) continue;
@@ -341,12 +344,12 @@ __global__ __launch_bounds__(BLOCK) void self_nn_kernel(const PairDesc *__restri
         int n = 0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            if (B.i[k] != own && n < 5) {
+            if (B.index(k) != own && n < 5) {
 #pragma unroll
                 for (int t = 0; t < 5; ++t)
                     if (t == n) {
-                        od[t] = B.d[k];
-                        oi[t] = B.i[k];
+                        od[t] = B.dist2(k);
+                        oi[t] = B.index(k);
                     }
                 ++n;
             }
