@@ -77,7 +77,7 @@ extern "C" {
 #define GPSCAL_EHIP (-3)    /* HIP runtime error (see gpscal_last_error)      */
 #define GPSCAL_ENOMEM (-4)  /* allocation failed                              */
 #define GPSCAL_ESIZE (-5)   /* track sizes differ (the reference exit(1)s, TC:46-50) */
-#define GPSCAL_ERANGE (-6)  /* output capacity too small                      */
+#define GPSCAL_ERANGE (-6)  /* output capacity too small / input beyond a size limit */
 #define GPSCAL_ECOMM (-7)   /* RCCL error                                     */
 
 #define GPSCAL_METHOD_UTM 0      /* "UTM"      (run.sh ctm, GP:498)  */
@@ -181,7 +181,10 @@ int gpscal_height_compensate(gpscal_ctx *ctx, const double *loam_xyzt, int n,
 
 /* ------------------------------------------------------------------ k-NN */
 /* Replaces pcl::KdTreeFLANN<PointType>::setInputCloud (LO:538-539,1119-1120;
- * LM:750-751).  Builds the multi-level uniform-grid index over m points. */
+ * LM:750-751).  Builds the multi-level uniform-grid index over m points.
+ * GPSCAL_ERANGE for a cloud of 2^27 points or more, or a set whose clouds hold 2^32 points over all levels (the
+ * index addresses a cloud's points by signed 32-bit byte offsets, a set's by 32-bit positions); the same limits hold
+ * for every cloud of gpscal_scan_batch_create. */
 int gpscal_knn_build(gpscal_ctx *ctx, const float *xyz, int m,
                      int stride_bytes, float cell_size_or_0,
                      gpscal_knn_index **index);
