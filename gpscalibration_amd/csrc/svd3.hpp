@@ -6,6 +6,27 @@
 
 namespace gpscal {
 
+// 1/sqrt(x), sqrt(x) and 1/x in float64 for the Jacobi steps: the hardware estimates (v_rsq_f64 / v_rcp_f64, ~2^-27)
+// + two Newton steps each, ~8 instructions against the ~25-30 of the library routines (which also serve denormals,
+// infinities and the last half ulp).  The solve kernel is ONE lane working through ~15 Jacobi steps of five such
+// operations each, every instruction a 4-cycle issue slot on a dependent chain: they were half of its SVD time.  The
+// arguments here are >= 1 (1 + t^2), sums of squares of a pre-scaled matrix's entries that the callers have compared
+// against `tiny`, or 2b with |b| >= tiny; results are good to ~1 ulp.
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * __fma_rn(-0.5 * x * y, y, 1.5);
+    y = y * __fma_rn(-0.5 * x * y, y, 1.5);
+    return y;
+}
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * __fma_rn(-x, r, 2.0);
+    r = r * __fma_rn(-x, r, 2.0);
+    return r;
+}
+
 __device__ __forceinline__ void rot_rows_T(double *W, int i, int j, double c, double s)
 {
 #pragma unroll
@@ -38,7 +59,7 @@ __device__ __forceinline__ bool jacobi_pair(double *W, double *U, double *V, int
     double t = wii + wjj, d = wji - wij;
     double c1 = 1.0, s1 = 0.0;
     if (fabs(d) >= tiny) {
-        double rh = rsqrt(t * t + d * d);  // matrix is pre-scaled: no overflow
+        double rh = fast_rsqrt(t * t + d * d);  // matrix is pre-scaled: no overflow
         c1 = t * rh;
         s1 = d * rh;
     }
@@ -47,9 +68,16 @@ __device__ __forceinline__ bool jacobi_pair(double *W, double *U, double *V, int
     double e = -s1 * wij + c1 * wjj;
     double cj = 1.0, sj = 0.0;
     if (fabs(b) >= tiny) {
-        double tau = (e - a) / (2.0 * b);
-        double tj = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-        cj = rsqrt(1.0 + tj * tj);
+        double tau = (e - a) * fast_rcp(2.0 * b);
+        tau = fmin(fmax(tau, -1e300), 1e300);  // (b may be as small as `tiny`: the product can overflow)
+        double tj;
+        if (fabs(tau) > 1e150) {  // 1 + tau^2 would overflow: the limit of the formula below
+            tj = 0.5 * fast_rcp(tau);
+        } else {
+            const double q = 1.0 + tau * tau;
+            tj = (tau >= 0.0 ? 1.0 : -1.0) * fast_rcp(fabs(tau) + q * fast_rsqrt(q));
+        }
+        cj = fast_rsqrt(1.0 + tj * tj);
         sj = tj * cj;
     }
     double cl = c1 * cj + s1 * sj;
