@@ -683,6 +683,23 @@ __device__ __forceinline__ void st_agent(T *p, T v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A pair's sums from the 64 lanes' shares of its workgroups' partial sums, in fixed order: the terms by the same LDS
+// transpose as in the step kernel (two passes of ~20 vector instructions instead of sixteen DPP wave reductions of 18),
+// the count by one DPP reduction.  Lane 0 ends up with the totals in a[] (the other lanes' a[] are unspecified).
+template <bool WEIGHTED>
+__device__ __forceinline__ void wave_totals(double (&a)[WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN], double *__restrict__ slab,
+                                            double *__restrict__ tot)
+{
+    using SL = SumLayout<WEIGHTED>;
+    constexpr int NACC = SL::NACC;
+    wave_reduce_terms<SL::NT>(&a[SL::FIRST], slab, [&](int k, double v) { tot[SL::FIRST + k] = v; });
+    const double cnt = wave_sum(a[SL::COUNT]);
+    if ((threadIdx.x & 63) == 0) tot[SL::COUNT] = cnt;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) a[k] = tot[k];
+}
+
 // From a pair's total sums to its new pose (TC:416-541 on 3-D data): one lane.  AGENT: the pose is read and written
 // with agent-scope accesses (the persistent kernel hands it from workgroup to workgroup).
 template <bool WEIGHTED, bool AGENT>
@@ -761,9 +778,10 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const PairDesc *__restric
 #pragma unroll
         for (int k = 0; k < NACC; ++k) a[k] += pp[k];
     }
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) a[k] = wave_sum(a[k]);
-    if (lane != 0) return;  // wave_sum leaves the totals in every lane
+    __shared__ double slab[8 * SLAB_PITCH];
+    __shared__ double tot[NACC];
+    wave_totals<WEIGHTED>(a, slab, tot);
+    if (lane != 0) return;
     solve_pose<WEIGHTED, false>(a, pose64 + (size_t)b * 16, pose32 + (size_t)b * 12,
                                 err_hist ? err_hist + (size_t)b * iters_cap + it : nullptr);
 }
@@ -839,8 +857,7 @@ __global__ __launch_bounds__(PERSIST_BLOCK) void icp_persistent_kernel(
 #pragma unroll
                 for (int k = 0; k < NACC; ++k) a[k] += ld_agent(pp + k);
             }
-#pragma unroll
-            for (int k = 0; k < NACC; ++k) a[k] = wave_sum(a[k]);
+            wave_totals<WEIGHTED>(a, &tslab[0][0][0], &wsum[0][0]);  // (wave 0's slab and row are free by now)
             if (lane == 0) {
                 solve_pose<WEIGHTED, true>(a, pose64 + (size_t)b * 16, pose32 + (size_t)b * 12,
                                            want_err ? err_hist + (size_t)b * iters_cap + it : nullptr);
@@ -1465,9 +1482,13 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
         if (cnt > 0 && hs / cnt < 0.25) B->ball_r = 4;
     }
     if (const char *e = getenv("GPSCAL_BALL_R")) B->ball_r = std::min(std::max(atoi(e), 0), 8);
-    // workgroup size of the step kernel: 256 threads while 128-thread workgroups would not fill the chip four times over
-    B->step_block = B->total_n >= 4ll * 128 * 8 * ctx->prop.multiProcessorCount ? 128 : 256;
-    if (const char *e = getenv("GPSCAL_STEP_BLOCK")) B->step_block = atoi(e) == 256 ? 256 : 128;
+    // workgroup size of the step kernel: 256 threads while 128-thread workgroups would not fill the chip four times over;
+    // 512 for one or two scans, where a run is a chain of launch latencies and the solve kernel's pass over the
+    // workgroups' partial sums is on it (one 65 536-point pair: 35.5 / 37.5 / 38.3 k iterations/s at 128 / 256 / 512)
+    B->step_block = B->total_n >= 4ll * 128 * 8 * ctx->prop.multiProcessorCount ? 128 : (B->total_n <= 131072 ? 512 : 256);
+    if (const char *e = getenv("GPSCAL_ICP_PERSISTENT"))
+        if (atoi(e) != 0) B->step_block = std::min(B->step_block, PERSIST_BLOCK);  // (that kernel is built for 256 threads)
+    if (const char *e = getenv("GPSCAL_STEP_BLOCK")) B->step_block = atoi(e) == 512 ? 512 : (atoi(e) == 256 ? 256 : 128);
     std::vector<int> bp, bf;
     for (int b = 0; b < np; ++b) {
         PairDesc &P = B->hpairs[b];
@@ -1657,7 +1678,8 @@ static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st, 
     if (nb <= 0) return;
 #define STEP(QPT, W, BALL)                                      \
     do {                                                        \
-        if (B->step_block == 256) STEP_BS(QPT, W, BALL, 256);   \
+        if (B->step_block == 512) STEP_BS(QPT, W, BALL, 512);   \
+        else if (B->step_block == 256) STEP_BS(QPT, W, BALL, 256); \
         else STEP_BS(QPT, W, BALL, 128);                        \
     } while (0)
 #define STEP_BS(QPT, W, BALL, BS)                                                                                        \
