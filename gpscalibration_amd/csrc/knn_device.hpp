@@ -667,7 +667,7 @@ __device__ __forceinline__ void ball_level(const GridDesc &G, const CellGeo &C, 
 // cells 2.5x .. R x 2.5x smaller than the level the 3x3x3 rule needs, i.e. fewer candidates under
 // the ball when the query is far from the surface the points sample.  Queries without a
 // candidate first climb the 3x3x3 blocks until they hold one.
-template <class BT, bool ALLOW_BALL = false>
+template <class BT, bool ALLOW_BALL = false, bool FLAT = false>
 __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__restrict__ sorted,
                                           const unsigned *__restrict__ cell_start, bool act, float px, float py,
                                           float pz, BT &B, int ball_r = 0, uint2 *__restrict__ slab = nullptr)
@@ -721,7 +721,7 @@ __device__ __forceinline__ void knn_query(const PairDesc &P, const float4 *__res
             STAT_WAVE(4, __popcll(__ballot(a)));
             STAT_WAVE(11 + min(l, 4), __popcll(__ballot(a)));
             if (!ALLOW_BALL || __ballot(a && far) == 0ull) {
-                if (!BT::COOP && slab)  // latency-bound callers hand in a wave-private slab (block3_level_flat)
+                if ((FLAT || !BT::COOP) && slab)  // latency-bound callers hand in a wave-private slab (block3_level_flat)
                     block3_level_flat(G, C, sorted, cell_start, a, px, py, pz, B, slab);
                 else
                     block3_level<BT, true>(G, C, sorted, cell_start, a, px, py, pz, B);

@@ -513,7 +513,7 @@ struct StepArgs {
     float4 *__restrict__ warm_q;  // last iteration's neighbour: x, y, z and its two certified radii in one word
     int *__restrict__ warm_i;     // ... and its index (read only by queries the first certificate does not settle)
 };
-template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK>
+template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK, bool FLAT = false>
 __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc &P, const float *T, int first, int src_n,
                                           long long src_off, long long tgt_off, int diag, int write_nn,
                                           double (&wsum)[STEP_BLOCK / 64][WEIGHTED ? NACC_WEIGHTED : NACC_PLAIN],
@@ -596,7 +596,8 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
         STAT_WAVE(17, __popcll(__ballot(ok && !need && B.pos != BestQ::WARM)));  // settled by tier 2 with a new neighbour
 #endif
         if (__ballot(need) != 0ull)  // wave-uniform: a settled wave skips the search's set-up as well
-            knn_query<BestQ, BALL>(P, sorted, cell_start, need, px, py, pz, B, diag >> 8);
+            knn_query<BestQ, BALL, FLAT>(P, sorted, cell_start, need, px, py, pz, B, diag >> 8,
+                                         FLAT ? reinterpret_cast<uint2 *>(&tslab[wave][0][0]) : nullptr);
         ok = ok && (t1 || B.index() != 0x7fffffff);  // (a query tier 1 settles may not have read its neighbour's index)
         if (ok && B.pos != BestQ::WARM) {
             // the neighbour changed: remember it and its radii for the next iteration
@@ -624,7 +625,11 @@ __device__ __forceinline__ unsigned step_body(const StepArgs &A, const PairDesc 
 #ifndef GPSCAL_STEP_MINW
 #define GPSCAL_STEP_MINW 1
 #endif
-template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK>
+// FLAT: the rows of a level are walked as per-lane lists (block3_level_flat, the wave's transpose slab holds them) --
+// the form for batches of one or two scans, where a launch is one wave per SIMD and its duration is the length of
+// the longest dependent chain of loads: a wave then pays its longest lane's list instead of the sum over the rows
+// of the longest run in each.
+template <int QPT, bool WEIGHTED, bool BALL, int STEP_BLOCK, bool FLAT = false>
 __global__ __launch_bounds__(STEP_BLOCK, GPSCAL_STEP_MINW) void icp_step_kernel(
     const PairDesc *__restrict__ pairs, const int *__restrict__ blk_pair, const int *__restrict__ blk_first,
     const float *__restrict__ src3, const double *__restrict__ wsrc, const float4 *__restrict__ sorted,
@@ -658,8 +663,8 @@ __global__ __launch_bounds__(STEP_BLOCK, GPSCAL_STEP_MINW) void icp_step_kernel(
         tgt_off = pairs[b].tgt_off;
     }
     const StepArgs A = {src3, wsrc, sorted, nbr, pt_r2, cell_start, nn_idx, nn_sqd, warm_q, warm_i};
-    step_body<QPT, WEIGHTED, BALL, STEP_BLOCK>(A, pairs[b], pose32 + (size_t)b * 12, first, src_n, src_off, tgt_off, diag,
-                                               write_nn, wsum, tslab);
+    step_body<QPT, WEIGHTED, BALL, STEP_BLOCK, FLAT>(A, pairs[b], pose32 + (size_t)b * 12, first, src_n, src_off, tgt_off,
+                                                     diag, write_nn, wsum, tslab);
     __syncthreads();
     if (threadIdx.x < NACC) {
         double v = 0.0;
@@ -1299,7 +1304,8 @@ struct gpscal_scan_batch {
     long long total_n = 0;
     bool weighted = false;
     int qpt = 1, nblk = 0, diag = 0;
-    int step_block = 128;  // threads per workgroup of icp_step_kernel (128 or 256, by batch size)
+    int step_block = 128;  // threads per workgroup of icp_step_kernel (128, 256 or 512, by batch size)
+    bool flat = false;     // small batch: the step's grid search walks per-lane row lists (latency-bound launches)
     bool persistent = false;  // small batch: all iterations of a run in ONE launch (icp_persistent_kernel)
     DevBuf<IcpCtl> ctl;
     int uni_n = 0, uni_m = 0, uni_bpp = 0;  // equal-sized scans stored back to back: workgroup slices by arithmetic
@@ -1482,13 +1488,24 @@ static int batch_setup_sources(gpscal_scan_batch *B, const float *src_xyz, int s
         if (cnt > 0 && hs / cnt < 0.25) B->ball_r = 4;
     }
     if (const char *e = getenv("GPSCAL_BALL_R")) B->ball_r = std::min(std::max(atoi(e), 0), 8);
-    // workgroup size of the step kernel: 256 threads while 128-thread workgroups would not fill the chip four times over;
-    // 512 for one or two scans, where a run is a chain of launch latencies and the solve kernel's pass over the
-    // workgroups' partial sums is on it (one 65 536-point pair: 35.5 / 37.5 / 38.3 k iterations/s at 128 / 256 / 512)
-    B->step_block = B->total_n >= 4ll * 128 * 8 * ctx->prop.multiProcessorCount ? 128 : (B->total_n <= 131072 ? 512 : 256);
+    // Workgroup size and row walk of the step kernel by batch size (tools/small_batch_probe.py, k iterations/s with
+    // 128 / 256 / 512 threads; "flat" = the per-lane row lists of block3_level_flat):
+    //   1 scan pair of 65 536 points    37.0 / 39.8 / 40.0, flat 40.1 / 43.2 / 43.4
+    //   2 pairs                          73.3 / 78.0 / 78.7, flat 78.4 / 84.4 / 86.3
+    //   8 pairs                          241 / 255 / 256,    flat 246 / 259 / 263
+    //   16 pairs                         432 / 450 / 418,    flat 415 / 415 / 401
+    //   32 pairs                         645 / 703 / 680,    flat 643 / 485 / 597
+    //   64 pairs                         128 and 256 threads within the replayed graph's run-to-run spread
+    // Up to 8 scans a launch is about one wave per SIMD and as long as its longest chain of dependent loads: large
+    // workgroups (fewer partial sums on the solve kernel's path) and flat row lists (a wave pays its longest lane's
+    // list, not the sum over the rows of the longest run in each); from 16 scans on the launches are throughput-bound
+    // and the pruned row-by-row walk wins.
+    B->step_block = B->total_n <= 524288 ? 512 : (B->total_n < 3ll * (1 << 20) ? 256 : 128);
+    B->flat = B->total_n <= 524288;
     if (const char *e = getenv("GPSCAL_ICP_PERSISTENT"))
         if (atoi(e) != 0) B->step_block = std::min(B->step_block, PERSIST_BLOCK);  // (that kernel is built for 256 threads)
     if (const char *e = getenv("GPSCAL_STEP_BLOCK")) B->step_block = atoi(e) == 512 ? 512 : (atoi(e) == 256 ? 256 : 128);
+    if (const char *e = getenv("GPSCAL_STEP_FLAT")) B->flat = atoi(e) != 0;
     std::vector<int> bp, bf;
     for (int b = 0; b < np; ++b) {
         PairDesc &P = B->hpairs[b];
@@ -1682,8 +1699,13 @@ static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st, 
         else if (B->step_block == 256) STEP_BS(QPT, W, BALL, 256); \
         else STEP_BS(QPT, W, BALL, 128);                        \
     } while (0)
-#define STEP_BS(QPT, W, BALL, BS)                                                                                        \
-    hipLaunchKernelGGL((icp_step_kernel<QPT, W, BALL, BS>), dim3(nb), dim3(BS), 0, st, B->pairs.p, B->blk_pair.p + b0, \
+#define STEP_BS(QPT, W, BALL, BS)                                         \
+    do {                                                                  \
+        if (QPT == 1 && B->flat) STEP_K(1, W, BALL, BS, true);            \
+        else STEP_K(QPT, W, BALL, BS, false);                             \
+    } while (0)
+#define STEP_K(QPT, W, BALL, BS, FLAT)                                                                                   \
+    hipLaunchKernelGGL((icp_step_kernel<QPT, W, BALL, BS, FLAT>), dim3(nb), dim3(BS), 0, st, B->pairs.p, B->blk_pair.p + b0, \
                        B->blk_first.p + b0, B->src3.p, B->wsorted.p, G.sorted.p, G.nbr.p, G.pt_r2.p, G.cell_start,   \
                        B->pose32.p, B->nn_idx.p, B->nn_sqd.p, B->warm_q.p, B->warm_i.p,                               \
                        B->partials.p + (size_t)b0 * (B->weighted ? NACC_WEIGHTED : NACC_PLAIN), nb,                  \
@@ -1698,6 +1720,7 @@ static void launch_step(gpscal_scan_batch *B, bool last, int c, hipStream_t st, 
     }
 #undef STEP
 #undef STEP_BS
+#undef STEP_K
 }
 
 static void launch_solve(gpscal_scan_batch *B, int it, int c, hipStream_t st)

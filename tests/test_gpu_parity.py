@@ -615,7 +615,7 @@ def test_icp_graph_chains_and_slices_agree_with_each_other_and_the_oracle(ctx, m
 
 
 def test_icp_runs_of_a_large_batch_repeat_bit_for_bit(ctx):
-    """A batch of a million source points (128-thread workgroups, four chains in the graph): every run from the same
+    """A batch of a million source points (256-thread workgroups, two chains in the graph): every run from the same
     pose gives the same bits -- the first run, later replays of the graph and the profiling mode's whole-batch
     launches -- and one pair is checked against the kd-tree oracle.  (Until the step kernel's sums were rewritten for
     instruction count, large batches switched to a second kernel in the converged iterations of later runs, which
