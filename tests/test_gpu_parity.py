@@ -567,7 +567,8 @@ def _ragged_batch(npairs, n):
 def test_icp_graph_chains_and_slices_agree_with_each_other_and_the_oracle(ctx, monkeypatch, ragged):
     """What the headline benchmark runs -- the captured graph with several step -> solve chains, chain-local block
     and partial-sum offsets, workgroup slices by arithmetic -- against the whole-batch launches of the profiling mode,
-    against one chain, against the table-driven slices, against the one-launch persistent kernel (GPSCAL_ICP_PERSISTENT=1:
+    against one chain, against the table-driven slices, against the other row walk of the grid search (per-lane lists /
+    row by row: the same exact search, so the same bits), against the one-launch persistent kernel (GPSCAL_ICP_PERSISTENT=1:
     all iterations of a small batch in one launch, bit-identical to the 256-thread graph path), and across the three workgroup sizes of the step kernel (last bits of the pose, never a correspondence); and against the kd-tree oracle.  12 pairs: two chains by default, four forced; the ragged batch has a
     five-point and a one-point source and a sparse target, so chains split unevenly and slices come from the table."""
     npairs, n, iters = 12, 4096, 12
@@ -577,7 +578,8 @@ def test_icp_graph_chains_and_slices_agree_with_each_other_and_the_oracle(ctx, m
         tg, to, sr, so, _ = synth.scan_batch(npairs, n)
     variants = {"default": {}, "persistent": {"GPSCAL_ICP_PERSISTENT": "1"}, "chains1": {"GPSCAL_ICP_CHAINS": "1"},
                 "chains4": {"GPSCAL_ICP_CHAINS": "4"}, "table": {"GPSCAL_ICP_UNIFORM": "0"},
-                "wg128": {"GPSCAL_STEP_BLOCK": "128", "GPSCAL_ICP_CHAINS": "4"}, "wg256": {"GPSCAL_STEP_BLOCK": "256"}}
+                "wg128": {"GPSCAL_STEP_BLOCK": "128", "GPSCAL_ICP_CHAINS": "4"}, "wg256": {"GPSCAL_STEP_BLOCK": "256"},
+                "rowwalk": {"GPSCAL_STEP_FLAT": "0"}}  # (a batch this small walks the rows of a level as per-lane lists by default)
     runs = {}
     for name, env in variants.items():
         for k, v in env.items():
@@ -595,7 +597,7 @@ def test_icp_graph_chains_and_slices_agree_with_each_other_and_the_oracle(ctx, m
             sb.set_pose(None)
             T_prev, _, _ = sb.icp(iters - 1)
         sb.close()
-    for name in ("chains1", "chains4", "table"):
+    for name in ("chains1", "chains4", "table", "rowwalk"):
         assert all(np.array_equal(a, b) for a, b in zip(runs["default"], runs[name])), name
     # (the persistent kernel is built for 256-thread workgroups; a batch this small takes 512 by default)
     assert all(np.array_equal(a, b) for a, b in zip(runs["wg256"], runs["persistent"]))
